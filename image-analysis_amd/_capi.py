@@ -1,0 +1,405 @@
+"""ctypes binding of include/lfa.h (liblfa_hip.so) plus the torch hand-off of device buffers.
+
+torch is used for exactly three things: owning device memory, host<->device copies, and naming the current HIP
+stream.  All arithmetic happens in the HIP library; if the library is missing this module raises at import --
+there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblfa_hip.so")
+
+LFA_U8, LFA_U16 = 0, 1
+DBG_MASK, DBG_OPENED, DBG_LABELS, DBG_TABLE, DBG_HIST = 0, 1, 2, 3, 4
+GRAY_NVARIANTS = 6
+
+# numpy mirrors of the C structs (align=True reproduces the C layout)
+STRIP_DT = np.dtype([("minr", "<i4"), ("maxr", "<i4"), ("minc", "<i4"), ("maxc", "<i4"), ("area", "<i4"),
+                     ("label", "<i4")], align=True)
+ROI_DT = np.dtype([("image", "<i4"), ("r0", "<i4"), ("r1", "<i4"), ("c0", "<i4"), ("c1", "<i4")], align=True)
+PEAKS_DT = np.dtype([("n_peaks", "<i4"), ("length", "<i4"), ("start", "<i4", (2,)), ("end", "<i4", (2,)),
+                     ("area", "<f8", (2,))], align=True)
+INFO_DT = np.dtype([("xmin", "<i4"), ("xmax", "<i4"), ("v_thr", "<i4"), ("x_thr", "<i4"),
+                    ("gmin", "<f8"), ("gmax", "<f8"), ("vmin", "<f8"), ("vmax", "<f8"), ("v_thr_f", "<f8"),
+                    ("g_thr", "<f8"), ("otsu_bin", "<i4"), ("all_equal", "<i4"), ("ambiguous", "<u4"),
+                    ("n_runs", "<i4"), ("n_labels", "<i4"), ("label00", "<i4"), ("n_candidates", "<i4"),
+                    ("n_accepted", "<i4"), ("n_strips", "<i4"), ("status", "<i4")], align=True)
+assert STRIP_DT.itemsize == 24 and ROI_DT.itemsize == 20 and PEAKS_DT.itemsize == 40 and INFO_DT.itemsize == 104
+
+
+class LfaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"liblfa_hip error {code}: {msg}")
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    lib.lfa_version.restype = i32
+    lib.lfa_last_error.restype = C.c_char_p
+    lib.lfa_create.argtypes = [i32, i32, i32, i32, i32, C.POINTER(vp)]
+    lib.lfa_destroy.argtypes = [vp]
+    lib.lfa_set_gamma_lut.argtypes = [vp, i32, vp, i32]
+    lib.lfa_set_gray_variant.argtypes = [vp, i32]
+    lib.lfa_detect_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
+    lib.lfa_profile_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp]
+    lib.lfa_peaks_batch.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.lfa_analyze_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]
+    lib.lfa_gaussian_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, dbl, vp, i32, vp, i32, vp]
+    lib.lfa_debug_fetch.argtypes = [vp, i32, i32, vp, i64, vp]
+    lib.lfa_sync.argtypes = [vp, vp]
+    for name in ("lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant", "lfa_detect_batch",
+                 "lfa_profile_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch", "lfa_debug_fetch",
+                 "lfa_sync"):
+        getattr(lib, name).restype = i32
+    return lib
+
+
+lib = _load()
+
+EXPORTED = ("lfa_version", "lfa_last_error", "lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant",
+            "lfa_detect_batch", "lfa_profile_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch",
+            "lfa_debug_fetch", "lfa_sync")
+
+
+def _check(rc):
+    if rc != 0:
+        raise LfaError(rc, lib.lfa_last_error().decode(errors="replace"))
+
+
+# ---- host-side tables that must carry the HOST numpy's bits ----------------------------------------------------------
+def numpy_gamma_lut_u8(gamma=0.4):
+    """skimage.exposure._adjust_gamma_u8 (exposure.py:611-617), built with this host's numpy."""
+    lut = 255 * 1 * (np.linspace(0, 1, 256) ** gamma)
+    return np.minimum(np.rint(lut), 255).astype("uint8")
+
+
+def numpy_gamma_lut_u16(gamma=0.4):
+    """adjust_gamma on every uint16 value (exposure.py:674-679), built with this host's numpy."""
+    x = np.arange(65536, dtype=np.uint16)
+    return (((x / 65535.0) ** gamma) * 65535.0 * 1).astype(np.uint16)
+
+
+def detect_gray_variant():
+    """Which rounding order `rgb @ coeffs` has in THIS host's numpy/BLAS (include/lfa.h LFA_GRAY_*).
+
+    Evaluates the candidate orders with exact float64 arithmetic on random triples and returns the first that
+    reproduces numpy's matmul on all of them (colorconv.py:876-877).  Raises if none does."""
+    import math
+    rng = np.random.default_rng(12345)
+    px = rng.integers(0, 256, size=(4096, 3), dtype=np.uint8)
+    x = np.multiply(px, 1.0 / 255, dtype=np.float64)
+    c = np.array([0.2125, 0.7154, 0.0721])
+    want = (x.reshape(64, 64, 3) @ c).reshape(-1)
+    fma = getattr(math, "fma", None)
+    if fma is None:
+        libm = C.CDLL("libm.so.6")
+        libm.fma.restype = C.c_double
+        libm.fma.argtypes = [C.c_double] * 3
+        fma = libm.fma
+    c0, c1, c2 = (float(v) for v in c)
+    forms = [
+        lambda a, b, d: fma(d, c2, fma(a, c0, b * c1)),
+        lambda a, b, d: (a * c0 + b * c1) + d * c2,
+        lambda a, b, d: fma(d, c2, fma(b, c1, a * c0)),
+        lambda a, b, d: fma(a, c0, fma(b, c1, d * c2)),
+        lambda a, b, d: a * c0 + (b * c1 + d * c2),
+        lambda a, b, d: fma(b, c1, a * c0) + d * c2,
+    ]
+    rows = [(float(a), float(b), float(d)) for a, b, d in x]
+    for v, f in enumerate(forms):
+        if all(f(*r) == w for r, w in zip(rows, want)):
+            return v
+    raise RuntimeError("this host's numpy matmul matches none of the known rgb2gray rounding orders")
+
+
+_GRAY_VARIANT = None
+
+
+def host_gray_variant():
+    global _GRAY_VARIANT
+    if _GRAY_VARIANT is None:
+        _GRAY_VARIANT = detect_gray_variant()
+    return _GRAY_VARIANT
+
+
+# ---- torch hand-off ----------------------------------------------------------------------------------------------------
+def _torch():
+    import torch
+    return torch
+
+
+def dev_bytes(nbytes, device):
+    torch = _torch()
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def to_device(arr: np.ndarray, device):
+    """numpy array (any dtype) -> 1-D uint8 CUDA tensor holding its bytes."""
+    torch = _torch()
+    a = np.ascontiguousarray(arr)
+    flat = a.view(np.uint8).reshape(-1) if a.size else np.zeros(0, np.uint8)
+    t = torch.from_numpy(flat.copy() if not flat.flags.writeable else flat)
+    return t.to(device, non_blocking=False)
+
+
+def from_device(t, dtype, count=None):
+    a = t.cpu().numpy()
+    n = (a.size // np.dtype(dtype).itemsize) if count is None else count
+    return a[: n * np.dtype(dtype).itemsize].view(dtype)
+
+
+def current_stream_ptr(device):
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def np_dtype_code(dt):
+    dt = np.dtype(dt)
+    if dt == np.uint8:
+        return LFA_U8
+    if dt == np.uint16:
+        return LFA_U16
+    raise TypeError(f"pixel dtype {dt} is not supported by the HIP path (uint8 and uint16 only)")
+
+
+def host_threshold(info_row, colour: bool):
+    """The reference's `threshold` value (detection.py:38/46) from an LfaImageInfo row.
+
+    Integer images: exact on the device.  Colour images: the device reports gmin, gmax and the Otsu bin; the float64
+    bin centre is rebuilt here with the HOST numpy's pow() so that it carries the same last bits as skimage's
+    (thresholding.py:378-381, exposure.py:298-301)."""
+    if not colour:
+        return int(info_row["v_thr"])
+    v = np.array([info_row["gmin"], info_row["gmax"]], dtype=np.float64) ** 0.4
+    if info_row["all_equal"]:
+        return float(v[0])
+    edges = np.linspace(v[0], v[1], 257)
+    k = int(info_row["otsu_bin"])
+    return float((edges[k] + edges[k + 1]) / 2.0)
+
+
+class Engine:
+    """One LfaHandle on one device.  Not thread-safe (like the reference's module globals)."""
+
+    def __init__(self, device=0, max_h=4096, max_w=4096, max_c=3, max_batch=16, gray_variant=None, host_luts=True):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the LFA path runs on the GPU only (no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        self.max_batch = max_batch
+        self._h = C.c_void_p()
+        _check(lib.lfa_create(device, max_h, max_w, max_c, max_batch, C.byref(self._h)))
+        if host_luts:
+            l8 = numpy_gamma_lut_u8()
+            l16 = numpy_gamma_lut_u16()
+            _check(lib.lfa_set_gamma_lut(self._h, LFA_U8, l8.ctypes.data, 256))
+            _check(lib.lfa_set_gamma_lut(self._h, LFA_U16, l16.ctypes.data, 65536))
+        self.gray_variant = host_gray_variant() if gray_variant is None else int(gray_variant)
+        _check(lib.lfa_set_gray_variant(self._h, self.gray_variant))
+
+    def close(self):
+        if self._h:
+            lib.lfa_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- raw calls on device tensors (uint8 byte tensors) --------------------------------------------------------------
+    def detect_raw(self, images_t, dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length, max_strips):
+        strips = dev_bytes(n * max_strips * STRIP_DT.itemsize, self.device)
+        counts = dev_bytes(n * 4, self.device)
+        info = dev_bytes(n * INFO_DT.itemsize, self.device)
+        _check(lib.lfa_detect_batch(self._h, images_t.data_ptr(), dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length,
+                                    strips.data_ptr(), max_strips, counts.data_ptr(), info.data_ptr(),
+                                    current_stream_ptr(self.device)))
+        return strips, counts, info
+
+    def analyze_raw(self, images_t, dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length, max_strips, stride):
+        torch = _torch()
+        strips = dev_bytes(n * max_strips * STRIP_DT.itemsize, self.device)
+        counts = dev_bytes(n * 4, self.device)
+        info = dev_bytes(n * INFO_DT.itemsize, self.device)
+        rois = dev_bytes(n * max_strips * ROI_DT.itemsize, self.device)
+        profiles = torch.empty(n * max_strips * stride, dtype=torch.float64, device=self.device)
+        peaks = dev_bytes(n * max_strips * PEAKS_DT.itemsize, self.device)
+        _check(lib.lfa_analyze_batch(self._h, images_t.data_ptr(), dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length,
+                                     strips.data_ptr(), max_strips, counts.data_ptr(), info.data_ptr(), rois.data_ptr(),
+                                     profiles.data_ptr(), stride, peaks.data_ptr(), current_stream_ptr(self.device)))
+        return strips, counts, info, rois, profiles, peaks
+
+    def profile_raw(self, images_t, dtype_code, n, H, W, Cc, rois_t, n_rois, inverse, rng, stride):
+        torch = _torch()
+        profiles = torch.empty(max(n_rois, 1) * stride, dtype=torch.float64, device=self.device)
+        peaks = dev_bytes(max(n_rois, 1) * PEAKS_DT.itemsize, self.device)
+        _check(lib.lfa_profile_batch(self._h, images_t.data_ptr(), dtype_code, n, H, W, Cc, rois_t.data_ptr(), n_rois,
+                                     int(bool(inverse)), int(rng), profiles.data_ptr(), stride, peaks.data_ptr(),
+                                     current_stream_ptr(self.device)))
+        return profiles, peaks
+
+    # -- numpy-level helpers -----------------------------------------------------------------------------------------
+    def _prep(self, images: np.ndarray):
+        images = np.asarray(images)
+        if images.ndim == 3:            # (n,H,W)
+            n, H, W = images.shape
+            Cc = 1
+        elif images.ndim == 4:
+            n, H, W, Cc = images.shape
+        else:
+            raise ValueError("expected a batch (n,H,W) or (n,H,W,3)")
+        return images, n, H, W, Cc, np_dtype_code(images.dtype)
+
+    def detect(self, images: np.ndarray, min_maxr, min_maxc, line_length=10, max_strips=64):
+        """Batch detect.  Returns (list of STRIP_DT arrays, INFO_DT array)."""
+        images, n, H, W, Cc, code = self._prep(images)
+        out_s, out_i = [], []
+        for b0 in range(0, n, self.max_batch):
+            b1 = min(n, b0 + self.max_batch)
+            t = to_device(images[b0:b1], self.device)
+            ms = max_strips
+            while True:
+                strips, counts, info = self.detect_raw(t, code, b1 - b0, H, W, Cc, int(min_maxr), int(min_maxc),
+                                                       int(line_length), ms)
+                inf = from_device(info, INFO_DT, b1 - b0)
+                if (inf["status"] & 1).any() and ms < 1024:
+                    ms = min(1024, ms * 4)
+                    continue
+                break
+            if (inf["status"] != 0).any():
+                raise LfaError(-3, f"detect overflow (status {inf['status'].tolist()}): more than 1024 strips per image")
+            cn = from_device(counts, np.int32, b1 - b0)
+            st = from_device(strips, STRIP_DT, (b1 - b0) * ms).reshape(b1 - b0, ms)
+            out_s += [st[i, :cn[i]].copy() for i in range(b1 - b0)]
+            out_i.append(inf.copy())
+        return out_s, np.concatenate(out_i)
+
+    def analyze(self, images: np.ndarray, min_maxr, min_maxc, line_length=10, max_strips=64):
+        """detect + image_analysis(strip, False) per strip.  Returns per image: (strips, [profile...], PEAKS_DT array)."""
+        images, n, H, W, Cc, code = self._prep(images)
+        stride = max(1, int(H * .6) + 1)
+        res = []
+        infos = []
+        for b0 in range(0, n, self.max_batch):
+            b1 = min(n, b0 + self.max_batch)
+            nb = b1 - b0
+            t = to_device(images[b0:b1], self.device)
+            strips, counts, info, rois, profiles, peaks = self.analyze_raw(t, code, nb, H, W, Cc, int(min_maxr),
+                                                                           int(min_maxc), int(line_length), max_strips, stride)
+            inf = from_device(info, INFO_DT, nb)
+            if (inf["status"] != 0).any():
+                raise LfaError(-3, f"analyze overflow (status {inf['status'].tolist()}); raise max_strips")
+            cn = from_device(counts, np.int32, nb)
+            st = from_device(strips, STRIP_DT, nb * max_strips).reshape(nb, max_strips)
+            pk = from_device(peaks, PEAKS_DT, nb * max_strips).reshape(nb, max_strips)
+            pr = profiles.cpu().numpy().reshape(nb, max_strips, stride)
+            for i in range(nb):
+                k = cn[i]
+                res.append((st[i, :k].copy(), [pr[i, q, :pk[i, q]["length"]].copy() for q in range(k)], pk[i, :k].copy()))
+            infos.append(inf.copy())
+        return res, np.concatenate(infos)
+
+    def profiles(self, images: np.ndarray, rois: np.ndarray, inverse=False, rng=15):
+        """Row-mean profiles + peaks of arbitrary ROIs (ROI_DT array) over a batch resident in one upload."""
+        images, n, H, W, Cc, code = self._prep(images)
+        if n > self.max_batch:
+            raise ValueError("batch larger than the engine's max_batch")
+        rois = np.ascontiguousarray(rois, dtype=ROI_DT)
+        n_rois = len(rois)
+        if n_rois == 0:
+            return [], np.zeros(0, PEAKS_DT)
+        stride = max(1, int((rois["r1"] - rois["r0"]).max()))
+        t = to_device(images, self.device)
+        rt = to_device(rois, self.device)
+        profiles, peaks = self.profile_raw(t, code, n, H, W, Cc, rt, n_rois, inverse, rng, stride)
+        pk = from_device(peaks, PEAKS_DT, n_rois)
+        pr = profiles.cpu().numpy().reshape(n_rois, stride)
+        return [pr[i, :max(0, pk[i]["length"])].copy() for i in range(n_rois)], pk.copy()
+
+    def peaks(self, profiles_list, inverse=False, window_size=25, two_peaks=False, rng=15):
+        n = len(profiles_list)
+        if n == 0:
+            return np.zeros(0, PEAKS_DT)
+        lens = np.array([len(p) for p in profiles_list], dtype=np.int32)
+        stride = max(1, int(lens.max()))
+        buf = np.zeros((n, stride), dtype=np.float64)
+        for i, p in enumerate(profiles_list):
+            buf[i, :len(p)] = np.asarray(p, dtype=np.float64)
+        bt = to_device(buf, self.device)
+        lt = to_device(lens, self.device)
+        out = dev_bytes(n * PEAKS_DT.itemsize, self.device)
+        _check(lib.lfa_peaks_batch(self._h, bt.data_ptr(), lt.data_ptr(), n, stride, int(bool(inverse)), int(window_size),
+                                   int(bool(two_peaks)), int(rng), out.data_ptr(), current_stream_ptr(self.device)))
+        return from_device(out, PEAKS_DT, n).copy()
+
+    def gaussian(self, images: np.ndarray, sigma=1.0, out_f32=False, host_weights=True):
+        torch = _torch()
+        images, n, H, W, Cc, code = self._prep(images)
+        if n > self.max_batch:
+            raise ValueError("batch larger than the engine's max_batch")
+        t = to_device(images, self.device)
+        out = torch.empty(n * H * W * Cc, dtype=torch.float32 if out_f32 else torch.float64, device=self.device)
+        wptr, radius = None, 0
+        if host_weights:
+            # scipy.ndimage._filters._gaussian_kernel1d (order 0) with this host's numpy exp()
+            radius = int(4.0 * float(sigma) + 0.5)
+            x = np.arange(-radius, radius + 1)
+            phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+            w = np.ascontiguousarray(phi / phi.sum(), dtype=np.float64)
+            wptr = w.ctypes.data
+        _check(lib.lfa_gaussian_batch(self._h, t.data_ptr(), code, n, H, W, Cc, float(sigma), wptr, radius, out.data_ptr(),
+                                      int(bool(out_f32)), current_stream_ptr(self.device)))
+        shape = (n, H, W) if Cc == 1 else (n, H, W, Cc)
+        return out.cpu().numpy().reshape(shape)
+
+    def debug(self, image_index, what, H, W):
+        torch = _torch()
+        if what in (DBG_MASK, DBG_OPENED):
+            out = torch.empty(H * W, dtype=torch.uint8, device=self.device)
+            nb = H * W
+        elif what == DBG_LABELS:
+            out = torch.empty(H * W, dtype=torch.int32, device=self.device)
+            nb = H * W * 4
+        else:
+            raise ValueError(what)
+        _check(lib.lfa_debug_fetch(self._h, image_index, what, out.data_ptr(), nb, current_stream_ptr(self.device)))
+        return out.cpu().numpy().reshape(H, W)
+
+    def debug_table(self, image_index, k):
+        torch = _torch()
+        out = torch.zeros(max(k, 1) * 5, dtype=torch.int32, device=self.device)
+        _check(lib.lfa_debug_fetch(self._h, image_index, DBG_TABLE, out.data_ptr(), max(k, 1) * 20,
+                                   current_stream_ptr(self.device)))
+        return out.cpu().numpy().reshape(-1, 5)[:k]
+
+    def sync(self):
+        _check(lib.lfa_sync(self._h, current_stream_ptr(self.device)))
+
+
+_ENGINES = {}
+
+
+def shared_engine(device=0, H=0, W=0):
+    """Process-wide engine per device, grown when a larger image arrives."""
+    e = _ENGINES.get(device)
+    if e is None or H > e._max_h or W > e._max_w:
+        if e is not None:
+            e.close()
+        mh, mw = max(H, 2048, getattr(e, "_max_h", 0)), max(W, 2048, getattr(e, "_max_w", 0))
+        e = Engine(device=device, max_h=mh, max_w=mw, max_c=3, max_batch=4)
+        e._max_h, e._max_w = mh, mw
+        _ENGINES[device] = e
+    return e

@@ -1,0 +1,318 @@
+// k_label.hip -- stages S4b-S6: vertical opening, connected components, label numbering, bbox / area  (gfx950)
+//
+// Reference (paths under /root/reference):
+//   opening   LFA-Image_Analysis/detection.py:60-63 -> skimage/morphology/binary.py:79-88, :138-145 ->
+//             scipy.ndimage.binary_erosion(border_value=True) / binary_dilation with a (line_length x 1) footprint
+//   label     detection.py:66 -> skimage/measure/_label.py:116-118 -> scipy.ndimage.label, 8-connectivity,
+//             ids 1..K in raster order of each component's first pixel
+//   bbox/area detection.py:71-73 -> skimage/measure/_regionprops.py:399-411
+//
+// The opening keeps exactly the vertical runs of the thresholded image with
+//     len + (run touches row 0 ? L/2 : 0) + (run touches row H-1 ? (L-1)/2 : 0) >= L          (L = line_length)
+// (erosion window [r-L/2, r+(L-1)/2] with True outside, dilation window mirrored with False outside; checked against
+// scipy in tests/test_oracle_golden.py).  So the opened image IS a list of vertical runs, and components are labelled
+// on runs instead of pixels: two runs in adjacent columns touch (8-connectivity) iff their row ranges, widened by one,
+// overlap.  Union-find links every run to the run of its component that holds the raster-first pixel
+// (smallest row*W + col), which is also what orders the label ids.  The label image is never materialised on the
+// hot path (lfa_debug_fetch paints it for tests).
+#include "lfa_internal.h"
+#include "lfa_device.h"
+
+namespace lfa {
+
+__device__ inline bool run_survives(int s, int e, int H, int L) {
+    const int len = e - s + 1;
+    const int eff = len + (s == 0 ? L / 2 : 0) + (e == H - 1 ? (L - 1) / 2 : 0);
+    return eff >= L;
+}
+
+// Walk column c of maskT top to bottom and call emit(start, end_inclusive) for every surviving run.
+template <class Emit>
+__device__ inline void column_runs(const uint64_t* colw, int HB, int H, int W, int L, const Emit& emit) {
+    int start = -1;
+    for (int rb = 0; rb < HB; ++rb) {
+        const uint64_t w = colw[(int64_t)rb * W];
+        uint64_t t = w ^ ((w << 1) | (start >= 0 ? 1ull : 0ull));       // bit k set: mask changes between row k-1 and k
+        while (t) {
+            const int b = __ffsll((unsigned long long)t) - 1;
+            t &= t - 1;
+            const int row = rb * 64 + b;
+            if (start < 0) start = row;
+            else {
+                if (run_survives(start, row - 1, H, L)) emit(start, row - 1);
+                start = -1;
+            }
+        }
+    }
+    if (start >= 0 && run_survives(start, H - 1, H, L)) emit(start, H - 1);
+}
+
+__global__ __launch_bounds__(256) void k_runs_count(Job j) {
+    const int img = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= j.W) return;
+    int n = 0;
+    column_runs(j.maskT + (int64_t)img * j.HB * j.W + c, j.HB, j.H, j.W, j.line_length, [&](int, int) { ++n; });
+    j.col_cnt[(int64_t)img * (j.W + 1) + c] = (uint32_t)n;
+}
+
+// exclusive scan of the W per-column counts of one image (in place), total at [W]
+__global__ __launch_bounds__(256) void k_col_scan(Job j) {
+    const int img = blockIdx.x;
+    uint32_t* cc = j.col_cnt + (int64_t)img * (j.W + 1);
+    __shared__ uint32_t part[256];
+    const int t = threadIdx.x;
+    const int seg = (j.W + 255) / 256;
+    const int b0 = min(j.W, t * seg), b1 = min(j.W, b0 + seg);
+    uint32_t sum = 0;
+    for (int k = b0; k < b1; ++k) sum += cc[k];
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 256; ++k) { const uint32_t v = part[k]; part[k] = acc; acc += v; }
+        cc[j.W] = acc;
+        j.info[img].n_runs = (int)acc;
+        if (acc > (uint32_t)j.run_cap) j.info[img].status |= 2;
+    }
+    __syncthreads();
+    uint32_t acc = part[t];
+    for (int k = b0; k < b1; ++k) { const uint32_t v = cc[k]; cc[k] = acc; acc += v; }
+}
+
+__global__ __launch_bounds__(256) void k_runs_fill(Job j) {
+    const int img = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= j.W) return;
+    const int64_t rbase = (int64_t)img * j.run_cap;
+    uint32_t idx = j.col_cnt[(int64_t)img * (j.W + 1) + c];
+    const uint32_t cap = (uint32_t)j.run_cap;
+    column_runs(j.maskT + (int64_t)img * j.HB * j.W + c, j.HB, j.H, j.W, j.line_length, [&](int s, int e) {
+        if (idx < cap) {
+            const int64_t i = rbase + idx;
+            j.run_se[i] = (uint32_t)s | ((uint32_t)e << 16);
+            j.run_col[i] = (uint16_t)c;
+            j.parent[i] = (int)idx;
+            j.area[i] = e - s + 1;
+            int4 bb; bb.x = s; bb.y = c; bb.z = e + 1; bb.w = c + 1;
+            *(int4*)(j.bbox + i * 4) = bb;
+        }
+        ++idx;
+    });
+}
+
+// ---- union-find on runs ---------------------------------------------------------------------------------------------
+// Links always point to the run with the smaller key (row_start * W + col), so chains strictly descend, there are no
+// cycles, and the root of a finished component is the run holding its raster-first pixel.  parent[] is read with
+// agent-scope relaxed atomic loads while other workgroups link (a stale "I am a root" only makes the CAS fail and hand
+// back the current parent); the CAS is the only writer.
+__device__ inline uint32_t run_key(const Job& j, int64_t rbase, int i) {
+    return (j.run_se[rbase + i] & 0xffffu) * (uint32_t)j.W + (uint32_t)j.run_col[rbase + i];
+}
+
+__device__ inline int uf_find_live(int* parent, int i) {
+    for (;;) {
+        const int p = __hip_atomic_load(&parent[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == i) return i;
+        i = p;
+    }
+}
+
+__device__ inline void uf_unite(const Job& j, int64_t rbase, int a, int b) {
+    int* parent = j.parent + rbase;
+    for (;;) {
+        a = uf_find_live(parent, a);
+        b = uf_find_live(parent, b);
+        if (a == b) return;
+        if (run_key(j, rbase, a) < run_key(j, rbase, b)) { const int t = a; a = b; b = t; }   // a: larger key
+        const int old = atomicCAS(&parent[a], a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_union(Job j) {
+    const int img = blockIdx.y;
+    const uint32_t* off = j.col_cnt + (int64_t)img * (j.W + 1);
+    const int64_t rbase = (int64_t)img * j.run_cap;
+    const int nr = min((int)off[j.W], j.run_cap);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) {
+        const int c = j.run_col[rbase + i];
+        if (c + 1 >= j.W) continue;
+        const uint32_t se = j.run_se[rbase + i];
+        const int a = (int)(se & 0xffffu), b = (int)(se >> 16);
+        int lo = (int)off[c + 1];
+        const int end = min((int)off[c + 2], j.run_cap);
+        int hi = end;
+        while (lo < hi) {                                   // first neighbour whose end >= a - 1
+            const int mid = (lo + hi) >> 1;
+            if ((int)(j.run_se[rbase + mid] >> 16) >= a - 1) hi = mid; else lo = mid + 1;
+        }
+        for (int q = lo; q < end; ++q) {
+            if ((int)(j.run_se[rbase + q] & 0xffffu) > b + 1) break;
+            uf_unite(j, rbase, i, q);
+        }
+    }
+}
+
+// after k_union: point every run at its root, fold area / bbox into the root, flag the root's first pixel
+__global__ __launch_bounds__(256) void k_flatten(Job j) {
+    const int img = blockIdx.y;
+    const uint32_t* off = j.col_cnt + (int64_t)img * (j.W + 1);
+    const int64_t rbase = (int64_t)img * j.run_cap;
+    const int nr = min((int)off[j.W], j.run_cap);
+    int* parent = j.parent + rbase;
+    uint64_t* fb = j.firstbits + (int64_t)img * j.H * j.W64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) {
+        int r = i;
+        for (;;) { const int p = __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (p == r) break; r = p; }
+        const uint32_t se = j.run_se[rbase + i];
+        const int s = (int)(se & 0xffffu), e = (int)(se >> 16), c = j.run_col[rbase + i];
+        if (r != i) {
+            __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&j.area[rbase + r], e - s + 1);
+            int* bb = j.bbox + (rbase + r) * 4;
+            atomicMin(&bb[0], s); atomicMin(&bb[1], c); atomicMax(&bb[2], e + 1); atomicMax(&bb[3], c + 1);
+        } else {
+            atomicOr((unsigned long long*)&fb[(int64_t)s * j.W64 + (c >> 6)], 1ull << (c & 63));
+        }
+    }
+}
+
+// exclusive prefix popcount over the first-pixel bitmap of one image -> rank of every component in raster order
+__global__ __launch_bounds__(1024) void k_rank_scan(Job j) {
+    const int img = blockIdx.x;
+    const int64_t nw = (int64_t)j.H * j.W64;
+    const uint64_t* fb = j.firstbits + (int64_t)img * nw;
+    uint32_t* wr = j.wordrank + (int64_t)img * nw;
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t seg = (nw + 1023) / 1024;
+    const int64_t b0 = min(nw, t * seg), b1 = min(nw, b0 + seg);
+    uint32_t sum = 0;
+    for (int64_t k = b0; k < b1; ++k) sum += __popcll(fb[k]);
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t acc = 0;
+        for (int k = 0; k < 1024; ++k) { const uint32_t v = part[k]; part[k] = acc; acc += v; }
+        j.info[img].n_labels = (int)acc;
+        j.info[img].label00 = (int)(fb[0] & 1ull);          // pixel (0,0) foreground <=> it is the first pixel of label 1
+    }
+    __syncthreads();
+    uint32_t acc = part[t];
+    for (int64_t k = b0; k < b1; ++k) { wr[k] = acc; acc += __popcll(fb[k]); }
+}
+
+__device__ inline int label_of_root(const Job& j, int img, int s, int c) {
+    const int64_t nw = (int64_t)j.H * j.W64;
+    const int64_t wi = (int64_t)img * nw + (int64_t)s * j.W64 + (c >> 6);
+    const uint64_t w = j.firstbits[wi];
+    return (int)(j.wordrank[wi] + __popcll(w & ((1ull << (c & 63)) - 1ull))) + 1;
+}
+
+__global__ __launch_bounds__(256) void k_label_roots(Job j) {
+    const int img = blockIdx.y;
+    const uint32_t* off = j.col_cnt + (int64_t)img * (j.W + 1);
+    const int64_t rbase = (int64_t)img * j.run_cap;
+    const int nr = min((int)off[j.W], j.run_cap);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) {
+        if (j.parent[rbase + i] != i) continue;
+        const uint32_t se = j.run_se[rbase + i];
+        const int lab = label_of_root(j, img, (int)(se & 0xffffu), j.run_col[rbase + i]);
+        j.root_of_label[rbase + lab - 1] = i;
+    }
+}
+
+hipError_t launch_label(const Job& j, hipStream_t s) {
+    const dim3 gcol((j.W + 255) / 256, j.n);
+    hipError_t e = hipMemsetAsync(j.firstbits, 0, (size_t)j.n * j.H * j.W64 * sizeof(uint64_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_runs_count, gcol, dim3(256), 0, s, j);
+    hipLaunchKernelGGL(k_col_scan, dim3(j.n), dim3(256), 0, s, j);
+    hipLaunchKernelGGL(k_runs_fill, gcol, dim3(256), 0, s, j);
+    int gx = (4096 + j.n - 1) / j.n;
+    if (gx < 8) gx = 8;
+    if (gx > 256) gx = 256;
+    const dim3 grun(gx, j.n);
+    hipLaunchKernelGGL(k_union, grun, dim3(256), 0, s, j);
+    hipLaunchKernelGGL(k_flatten, grun, dim3(256), 0, s, j);
+    hipLaunchKernelGGL(k_rank_scan, dim3(j.n), dim3(1024), 0, s, j);
+    hipLaunchKernelGGL(k_label_roots, grun, dim3(256), 0, s, j);
+    return hipGetLastError();
+}
+
+// ---- diagnostics: paint masks / labels / table for the parity tests ------------------------------------------------
+__global__ void k_dbg_mask(Job j, int img, uint8_t* out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)j.H * j.W) return;
+    const int r = (int)(p / j.W), c = (int)(p % j.W);
+    const uint64_t w = j.maskT[((int64_t)img * j.HB + (r >> 6)) * j.W + c];
+    out[p] = (uint8_t)((w >> (r & 63)) & 1ull);
+}
+
+__global__ void k_dbg_paint(Job j, int img, int what, void* out) {
+    const uint32_t* off = j.col_cnt + (int64_t)img * (j.W + 1);
+    const int64_t rbase = (int64_t)img * j.run_cap;
+    const int nr = min((int)off[j.W], j.run_cap);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) {
+        const uint32_t se = j.run_se[rbase + i];
+        const int s = (int)(se & 0xffffu), e = (int)(se >> 16), c = j.run_col[rbase + i];
+        if (what == LFA_DBG_OPENED) {
+            for (int r = s; r <= e; ++r) ((uint8_t*)out)[(int64_t)r * j.W + c] = 1;
+        } else {
+            const int root = j.parent[rbase + i];
+            const uint32_t rse = j.run_se[rbase + root];
+            const int lab = label_of_root(j, img, (int)(rse & 0xffffu), j.run_col[rbase + root]);
+            for (int r = s; r <= e; ++r) ((int32_t*)out)[(int64_t)r * j.W + c] = lab;
+        }
+    }
+}
+
+__global__ void k_dbg_table(Job j, int img, int32_t* out, int kmax) {
+    const int64_t rbase = (int64_t)img * j.run_cap;
+    const int K = min(j.info[img].n_labels, kmax);
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < K; l += gridDim.x * blockDim.x) {
+        const int root = j.root_of_label[rbase + l];
+        const int* bb = j.bbox + (rbase + root) * 4;
+        out[l * 5 + 0] = bb[0]; out[l * 5 + 1] = bb[1]; out[l * 5 + 2] = bb[2]; out[l * 5 + 3] = bb[3];
+        out[l * 5 + 4] = j.area[rbase + root];
+    }
+}
+
+hipError_t launch_debug(const Job& j, int image, int what, void* out, int64_t out_bytes, hipStream_t s) {
+    const int64_t npix = (int64_t)j.H * j.W;
+    hipError_t e;
+    switch (what) {
+        case LFA_DBG_MASK:
+            if (out_bytes < npix) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(k_dbg_mask, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, j, image, (uint8_t*)out);
+            break;
+        case LFA_DBG_OPENED:
+            if (out_bytes < npix) return hipErrorInvalidValue;
+            e = hipMemsetAsync(out, 0, npix, s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_dbg_paint, dim3(256), dim3(256), 0, s, j, image, what, out);
+            break;
+        case LFA_DBG_LABELS:
+            if (out_bytes < npix * 4) return hipErrorInvalidValue;
+            e = hipMemsetAsync(out, 0, npix * 4, s);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_dbg_paint, dim3(256), dim3(256), 0, s, j, image, what, out);
+            break;
+        case LFA_DBG_TABLE:
+            hipLaunchKernelGGL(k_dbg_table, dim3(64), dim3(256), 0, s, j, image, (int32_t*)out, (int)(out_bytes / 20));
+            break;
+        case LFA_DBG_HIST: {
+            const int64_t nb = out_bytes / 4 < j.hist_stride ? out_bytes / 4 : j.hist_stride;
+            e = hipMemcpyAsync(out, j.hist + (int64_t)image * j.hist_stride, nb * 4, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return e;
+            break;
+        }
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace lfa

@@ -1,0 +1,148 @@
+// k_mask.hip -- stage S4a: threshold compare, written as VERTICAL 64-row bit words  (gfx950)
+//
+// mask = adjust_gamma(gray, 0.4) > threshold_otsu(...)   (LFA-Image_Analysis/detection.py:39, :47), evaluated as an
+// integer compare `pixel > x_thr` (2-D images) or a float64 compare `gray > g_thr` (colour), see k_threshold.hip.
+//
+// Layout: maskT[image][rb][c] is a uint64 whose bit k is mask[rb*64 + k][c].  Lanes run along c, so the image is read
+// in whole row segments (coalesced) and the words are written coalesced; the opening and the run extraction that
+// follow work along columns and get 64 rows per load.
+#include "lfa_internal.h"
+#include "lfa_device.h"
+
+namespace lfa {
+
+// MODE 0: uint8 2-D, 1: uint16 2-D, 2: uint8 colour.  VEC: 16 pixels per lane per row through 16-byte loads.
+template <int MODE, int V, bool VEC>
+__global__ __launch_bounds__(256) void k_mask(Job j) {
+    const int img = blockIdx.y;
+    const LfaImageInfo inf = j.info[img];
+    const uint8_t* base = j.images + (int64_t)img * j.img_bytes;
+    const int H = j.H, W = j.W;
+    const int x_thr = inf.x_thr;
+    const double g_thr = inf.g_thr;
+    // first double above g_thr (for the ambiguity census only)
+    const long long gb = __double_as_longlong(g_thr);
+    const double g_next = (gb >= 0 && gb < 0x7ff0000000000000LL) ? __longlong_as_double(gb + 1) : g_thr;
+    uint64_t* out = j.maskT + (int64_t)img * j.HB * W;
+    uint32_t amb = 0;
+
+    if (VEC) {
+        const int ncg = W >> 4;
+        const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (item < (int64_t)j.HB * ncg) {
+            const int rb = (int)(item / ncg), cg = (int)(item % ncg);
+            const int r0 = rb * 64;
+            const int rows = min(64, H - r0);
+            uint32_t lo[16], hi[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { lo[k] = 0; hi[k] = 0; }
+            const int64_t px_bytes = (MODE == 2) ? 3 : (MODE == 1 ? 2 : 1);
+            const uint8_t* p = base + ((int64_t)r0 * W + (int64_t)cg * 16) * px_bytes;
+            const int64_t row_bytes = (int64_t)W * px_bytes;
+            auto row_bits = [&](const uint8_t* q) -> uint32_t {
+                uint32_t bits = 0;
+                if (MODE == 0) {
+                    const uint4 a = *(const uint4*)q;
+                    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) bits |= ((int)byte_of(w, k) > x_thr ? 1u : 0u) << k;
+                } else if (MODE == 1) {
+                    const uint4 a = ((const uint4*)q)[0], b = ((const uint4*)q)[1];
+                    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int x = (int)((w[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
+                        bits |= (x > x_thr ? 1u : 0u) << k;
+                    }
+                } else {
+                    uint32_t w[12];
+                    load48(q, w);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const double g = gray_u8<V>(byte_of(w, 3 * k), byte_of(w, 3 * k + 1), byte_of(w, 3 * k + 2));
+                        bits |= (g > g_thr ? 1u : 0u) << k;
+                        amb += near_rel(g, g_next) ? 1u : 0u;
+                    }
+                }
+                return bits;
+            };
+            const int rows_lo = min(rows, 32);
+#pragma unroll 2
+            for (int r = 0; r < rows_lo; ++r) {
+                const uint32_t bits = row_bits(p + (int64_t)r * row_bytes);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lo[k] |= ((bits >> k) & 1u) << r;
+            }
+#pragma unroll 2
+            for (int r = 32; r < rows; ++r) {
+                const uint32_t bits = row_bits(p + (int64_t)r * row_bytes);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) hi[k] |= ((bits >> k) & 1u) << (r - 32);
+            }
+            uint64_t* o = out + (int64_t)rb * W + cg * 16;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                uint4 v;
+                v.x = lo[k]; v.y = hi[k]; v.z = lo[k + 1]; v.w = hi[k + 1];
+                *(uint4*)(o + k) = v;
+            }
+        }
+    } else {
+        const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (item < (int64_t)j.HB * W) {
+            const int rb = (int)(item / W), c = (int)(item % W);
+            const int r0 = rb * 64;
+            const int rows = min(64, H - r0);
+            uint64_t acc = 0;
+            for (int r = 0; r < rows; ++r) {
+                const int64_t px = (int64_t)(r0 + r) * W + c;
+                bool bit;
+                if (MODE == 0) bit = (int)base[px] > x_thr;
+                else if (MODE == 1) bit = (int)((const uint16_t*)base)[px] > x_thr;
+                else {
+                    const double g = gray_u8<V>(base[3 * px], base[3 * px + 1], base[3 * px + 2]);
+                    bit = g > g_thr;
+                    amb += near_rel(g, g_next) ? 1u : 0u;
+                }
+                acc |= (uint64_t)(bit ? 1 : 0) << r;
+            }
+            out[(int64_t)rb * W + c] = acc;
+        }
+    }
+    if (MODE == 2) {
+        amb = wave_sum_u32(amb);
+        if ((threadIdx.x & 63) == 0 && amb) atomicAdd(&j.info[img].ambiguous, amb);
+    }
+}
+
+template <int MODE, int V>
+static void launch_mode(const Job& j, hipStream_t s) {
+    const bool vec = j.aligned16 && (j.W % 16 == 0);
+    if (vec) {
+        const int64_t items = (int64_t)j.HB * (j.W >> 4);
+        hipLaunchKernelGGL((k_mask<MODE, V, true>), dim3((unsigned)((items + 255) / 256), j.n), dim3(256), 0, s, j);
+    } else {
+        const int64_t items = (int64_t)j.HB * j.W;
+        hipLaunchKernelGGL((k_mask<MODE, V, false>), dim3((unsigned)((items + 255) / 256), j.n), dim3(256), 0, s, j);
+    }
+}
+
+hipError_t launch_mask(const Job& j, hipStream_t s) {
+    if (j.C == 3) {
+        switch (j.gray_variant) {
+            case 0: launch_mode<2, 0>(j, s); break;
+            case 1: launch_mode<2, 1>(j, s); break;
+            case 2: launch_mode<2, 2>(j, s); break;
+            case 3: launch_mode<2, 3>(j, s); break;
+            case 4: launch_mode<2, 4>(j, s); break;
+            default: launch_mode<2, 5>(j, s); break;
+        }
+    } else if (j.dtype == LFA_U8) {
+        launch_mode<0, 0>(j, s);
+    } else {
+        launch_mode<1, 0>(j, s);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace lfa

@@ -1,0 +1,183 @@
+// k_regions.hip -- stage S7: region test, duplicate rejection, outlier removal, sort, analysis windows  (gfx950)
+//
+// Reference: /root/reference/LFA-Image_Analysis/detection.py:67-93 (loop over regionprops in label order),
+//            :118-127 (check_duplicate), :138-153 (remove_outliers), :215-216 (analysis window of a strip).
+// Means are exact integer sums followed by the reference's float64 divisions (np.mean of an integer array sums in
+// float64, which is exact below 2^53).
+#include "lfa_internal.h"
+#include "lfa_device.h"
+
+namespace lfa {
+
+constexpr int kMaxStripsLds = 1024;
+
+// labels with area >= 100, ascending, one block per image
+__global__ __launch_bounds__(256) void k_candidates(Job j) {
+    const int img = blockIdx.x;
+    const int64_t rbase = (int64_t)img * j.run_cap;
+    const int K = j.info[img].n_labels;
+    __shared__ int wcnt[4];
+    __shared__ int base;
+    const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+    if (t == 0) base = 0;
+    __syncthreads();
+    for (int l0 = 0; l0 < K; l0 += 256) {
+        const int l = l0 + t;
+        bool flag = false;
+        if (l < K) flag = j.area[rbase + j.root_of_label[rbase + l]] >= kAreaMin;
+        const unsigned long long bal = __ballot(flag);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        __syncthreads();
+        int offs = base;
+        for (int k = 0; k < wv; ++k) offs += wcnt[k];
+        if (flag) j.cand[rbase + offs + __popcll(bal & ((1ull << lane) - 1ull))] = l + 1;
+        __syncthreads();
+        if (t == 0) base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    if (t == 0) j.info[img].n_candidates = base;
+}
+
+// mean of the ORIGINAL image over the expanded, clipped box of every candidate; flag = mean > label id at (0,0)
+__global__ __launch_bounds__(256) void k_box_means(Job j) {
+    const int img = blockIdx.y;
+    const int64_t rbase = (int64_t)img * j.run_cap;
+    const int nc = j.info[img].n_candidates;
+    const double bg = (double)j.info[img].label00;
+    const uint8_t* base = j.images + (int64_t)img * j.img_bytes;
+    __shared__ unsigned long long part[4][3];
+    const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
+    for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
+        const int root = j.root_of_label[rbase + j.cand[rbase + ci] - 1];
+        const int* bb = j.bbox + (rbase + root) * 4;
+        const int minr = bb[0], minc = bb[1];
+        int maxr = max(bb[2], minr + j.min_maxr), maxc = max(bb[3], minc + j.min_maxc);
+        maxr = min(maxr, j.H); maxc = min(maxc, j.W);
+        unsigned long long s0 = 0, s1 = 0, s2 = 0;
+        for (int r = minr + wv; r < maxr; r += 4) {
+            const int64_t rowpx = (int64_t)r * j.W;
+            for (int c = minc + lane; c < maxc; c += 64) {
+                const int64_t px = rowpx + c;
+                if (j.C == 3) { s0 += base[3 * px]; s1 += base[3 * px + 1]; s2 += base[3 * px + 2]; }
+                else if (j.dtype == LFA_U8) s0 += base[px];
+                else s0 += ((const uint16_t*)base)[px];
+            }
+        }
+        s0 = wave_sum_u64(s0); s1 = wave_sum_u64(s1); s2 = wave_sum_u64(s2);
+        if (lane == 0) { part[wv][0] = s0; part[wv][1] = s1; part[wv][2] = s2; }
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long a0 = 0, a1 = 0, a2 = 0;
+            for (int k = 0; k < 4; ++k) { a0 += part[k][0]; a1 += part[k][1]; a2 += part[k][2]; }
+            const double cnt = (double)((long long)(maxr - minr) * (long long)(maxc - minc));
+            double m;
+            if (j.C == 3) {
+                const double m0 = (double)a0 / cnt, m1 = (double)a1 / cnt, m2 = (double)a2 / cnt;
+                m = ((m0 + m1) + m2) / 3.0;
+            } else {
+                m = (double)a0 / cnt;
+            }
+            j.cand_ok[rbase + ci] = (m > bg) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+struct Acc { int minr, maxr, minc, maxc, area, label; };
+
+// one wave per image: accept in label order with the inclusive-overlap test, drop wide outliers, stable sort
+__global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
+    const int img = blockIdx.x;
+    const int64_t rbase = (int64_t)img * j.run_cap;
+    LfaImageInfo* inf = &j.info[img];
+    const int nc = inf->n_candidates;
+    const int lane = threadIdx.x;
+    const int cap = min(j.max_strips, kMaxStripsLds);
+    __shared__ Acc acc[kMaxStripsLds];
+    __shared__ Acc kept[kMaxStripsLds];
+    int na = 0;
+    int status = 0;
+    for (int ci = 0; ci < nc; ++ci) {
+        if (!j.cand_ok[rbase + ci]) continue;                 // uniform: every lane reads the same byte
+        const int lab = j.cand[rbase + ci];
+        const int root = j.root_of_label[rbase + lab - 1];
+        const int* bb = j.bbox + (rbase + root) * 4;
+        const int minr = bb[0], minc = bb[1];
+        const int maxr = max(bb[2], minr + j.min_maxr), maxc = max(bb[3], minc + j.min_maxc);
+        bool hit = false;
+        for (int k = lane; k < na; k += 64) {
+            const Acc a = acc[k];
+            hit |= (minr <= a.maxr && maxr >= a.minr && minc <= a.maxc && maxc >= a.minc);
+        }
+        if (__any(hit)) continue;
+        if (na < cap) {
+            if (lane == 0) {
+                Acc a; a.minr = minr; a.maxr = maxr; a.minc = minc; a.maxc = maxc;
+                a.area = j.area[rbase + root]; a.label = lab;
+                acc[na] = a;
+            }
+            __syncthreads();
+            ++na;
+        } else {
+            status |= 1;                                      // out of room: later duplicate tests would be incomplete
+            ++na;
+            break;
+        }
+    }
+    __syncthreads();
+    const int na_c = min(na, cap);
+    // remove_outliers: width uses the expanded maxc (already applied)
+    int wmin = 0x7fffffff;
+    for (int k = lane; k < na_c; k += 64) wmin = min(wmin, acc[k].maxc - acc[k].minc);
+    wmin = wave_min_i32(wmin);
+    __shared__ int nk_s;
+    if (lane == 0) {
+        int nk = 0;
+        for (int k = 0; k < na_c; ++k)
+            if ((long long)(acc[k].maxc - acc[k].minc) <= 2ll * wmin) kept[nk++] = acc[k];
+        nk_s = nk;
+    }
+    __syncthreads();
+    const int nk = nk_s;
+    // stable sort by (minc, maxc): rank by counting
+    LfaStrip* out = o.strips + (int64_t)img * j.max_strips;
+    LfaRoi* rois = o.rois ? o.rois + (int64_t)img * j.max_strips : nullptr;
+    for (int i = lane; i < nk; i += 64) {
+        const Acc a = kept[i];
+        int rank = 0;
+        for (int k = 0; k < nk; ++k) {
+            const Acc b = kept[k];
+            const bool less = (b.minc < a.minc) || (b.minc == a.minc && (b.maxc < a.maxc || (b.maxc == a.maxc && k < i)));
+            rank += less ? 1 : 0;
+        }
+        LfaStrip sref;
+        sref.minr = a.minr; sref.maxr = a.maxr; sref.minc = a.minc; sref.maxc = a.maxc; sref.area = a.area; sref.label = a.label;
+        out[rank] = sref;
+        if (rois) {
+            // window of image_analysis(strip, selected=False): detection.py:215-216 on the numpy-clipped crop
+            const int h = min(a.maxr, j.H) - a.minr, w = min(a.maxc, j.W) - a.minc;
+            LfaRoi r;
+            r.image = img;
+            r.r0 = a.minr + (int)((double)h * .25); r.r1 = a.minr + (int)((double)h * .6);
+            r.c0 = a.minc + (int)((double)w * .3);  r.c1 = a.minc + (int)((double)w * .7);
+            rois[rank] = r;
+        }
+    }
+    if (lane == 0) {
+        inf->n_accepted = na; inf->n_strips = nk; inf->status |= status;
+        o.counts[img] = nk;
+        if (o.info) o.info[img] = *inf;
+    }
+}
+
+hipError_t launch_regions(const Job& j, const OutPtrs& o, hipStream_t s) {
+    hipLaunchKernelGGL(k_candidates, dim3(j.n), dim3(256), 0, s, j);
+    int gx = (4096 + j.n - 1) / j.n;
+    if (gx < 4) gx = 4;
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(k_box_means, dim3(gx, j.n), dim3(256), 0, s, j);
+    hipLaunchKernelGGL(k_finalize, dim3(j.n), dim3(64), 0, s, j, o);
+    return hipGetLastError();
+}
+
+}  // namespace lfa

@@ -1,0 +1,242 @@
+// lfa_algo.h -- sequential arithmetic shared by the HIP kernels (and compiled for the host by the unit-test shim
+// tests/hostcheck/, which exists only to exercise these functions on a machine without a GPU).
+//
+// Everything here must reproduce numpy's results bit for bit, so this file is compiled with -ffp-contract=off and
+// spells out every rounding step.  References (relative to /root/reference):
+//   analyze_peaks / image_analysis peak logic   LFA-Image_Analysis/detection.py:221-245, :257-281, :283-316
+//   float Otsu                                   image-analysis/lib/python3.10/site-packages/skimage/filters/thresholding.py:364-381
+//   np.histogram edges (linspace)                .../numpy/core/function_base.py:145-167
+//   np.add.reduce pairwise summation             numpy/core/src/umath/loops_utils.h.src (*_pairwise_sum), not vendored as source
+//                                                in the reference tree; order pinned empirically (tests/test_host_algo.py)
+#ifndef LFA_ALGO_H_
+#define LFA_ALGO_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define LFA_HD __host__ __device__ inline
+#else
+#define LFA_HD inline
+#endif
+
+namespace lfa {
+
+// ---------------------------------------------------------------------------------------------------------------
+// numpy's pairwise sum of f(0..n-1).  n < 8: plain loop; n <= 128: eight running sums, combined as a tree, then the
+// remainder one by one; larger: split at n/2 rounded down to a multiple of 8.
+// ---------------------------------------------------------------------------------------------------------------
+template <class F>
+LFA_HD double np_pairwise(const F& f, int off, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res = res + f(off + i);
+        return res;
+    }
+    if (n <= 128) {
+        double r0 = f(off + 0), r1 = f(off + 1), r2 = f(off + 2), r3 = f(off + 3);
+        double r4 = f(off + 4), r5 = f(off + 5), r6 = f(off + 6), r7 = f(off + 7);
+        int i = 8;
+        const int lim = n - (n % 8);
+        for (; i < lim; i += 8) {
+            r0 = r0 + f(off + i + 0); r1 = r1 + f(off + i + 1); r2 = r2 + f(off + i + 2); r3 = r3 + f(off + i + 3);
+            r4 = r4 + f(off + i + 4); r5 = r5 + f(off + i + 5); r6 = r6 + f(off + i + 6); r7 = r7 + f(off + i + 7);
+        }
+        double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < n; ++i) res = res + f(off + i);
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const double a = np_pairwise(f, off, n2);
+    const double b = np_pairwise(f, off + n2, n - n2);
+    return a + b;
+}
+
+struct ArrAt {
+    const double* p;
+    LFA_HD double operator()(int i) const { return p[i]; }
+};
+
+// np.trapz(y[0..n)) with dx = 1:  sum((1.0 * (y[1:] + y[:-1])) / 2.0)
+struct TrapzAt {
+    const double* y;
+    LFA_HD double operator()(int i) const { return (1.0 * (y[i + 1] + y[i])) / 2.0; }
+};
+
+// np.linspace(start, stop, num)[i]   (numpy/core/function_base.py:145-167)
+struct Linspace {
+    double start, stop, step, delta;
+    int num, div;
+    bool step_zero;
+    LFA_HD Linspace(double a, double b, int n) : start(a), stop(b), num(n) {
+        div = n - 1;
+        delta = b - a;
+        step = (div > 0) ? delta / (double)div : 0.0;
+        step_zero = (div > 0) && (step == 0.0);
+    }
+    LFA_HD double operator()(int i) const {
+        if (num > 1 && i == num - 1) return stop;
+        double y = (double)i;
+        if (div > 0) {
+            if (step_zero) { y = y / (double)div; y = y * delta; }
+            else           { y = y * step; }
+        } else {
+            y = y * delta;
+        }
+        return y + start;
+    }
+};
+
+struct TrapzLin {
+    Linspace l;
+    LFA_HD double operator()(int i) const { return (1.0 * (l(i + 1) + l(i))) / 2.0; }
+};
+
+LFA_HD bool lfa_isnan(double x) { return x != x; }
+
+// np.argmax / np.argmin on float64 (first extremum; the first NaN wins)
+LFA_HD int np_argext(const double* p, int n, bool want_min) {
+    double m = p[0];
+    int idx = 0;
+    if (lfa_isnan(m)) return 0;
+    for (int i = 1; i < n; ++i) {
+        const double x = p[i];
+        const bool upd = want_min ? !(x >= m) : !(x <= m);
+        if (upd) {
+            m = x; idx = i;
+            if (lfa_isnan(m)) break;
+        }
+    }
+    return idx;
+}
+
+struct Peak { int start, end; double area; };
+
+// detection.py:285-316 given the extremum index (detection.py:284)
+LFA_HD Peak analyze_peaks_at(const double* p, int n, int peak, bool inverse, int window) {
+    int ws = peak - window; if (ws < 0) ws = 0;
+    int we = peak + window + 1; if (we > n) we = n;
+    const double thr = np_pairwise(ArrAt{p}, ws, we - ws) / (double)(we - ws);
+    int s = peak, e = peak;
+    if (inverse) {
+        while (s > 0 && (p[s] <= p[s - 1] || p[s] < thr)) --s;
+        while (e < n - 1 && (p[e] <= p[e + 1] || p[e] < thr)) ++e;
+    } else {
+        while (s > 0 && (p[s] >= p[s - 1] || p[s] > thr)) --s;
+        while (e < n - 1 && (p[e] >= p[e + 1] || p[e] > thr)) ++e;
+    }
+    const int m = e - s + 1;
+    const double seg = np_pairwise(TrapzAt{p + s}, 0, m - 1);
+    const double base = np_pairwise(TrapzLin{Linspace(p[s], p[e], m)}, 0, m - 1);
+    Peak r;
+    r.start = s; r.end = e;
+    r.area = inverse ? (base - seg) : (seg - base);
+    return r;
+}
+
+struct SeqArgExt {
+    LFA_HD int operator()(const double* p, int n, bool want_min) const { return np_argext(p, n, want_min); }
+};
+
+LFA_HD Peak analyze_peaks(const double* p, int n, bool inverse, int window) {
+    return analyze_peaks_at(p, n, np_argext(p, n, inverse), inverse, window);
+}
+
+// Python slice p[:k] -> length
+LFA_HD int py_head_len(int k, int n) {
+    if (k < 0) { k += n; if (k < 0) k = 0; }
+    if (k > n) k = n;
+    return k;
+}
+
+struct TwoPeaks { int n; Peak pk[2]; };
+
+// detection.py:221-245 (fallback = true, image_analysis) and :257-281 (fallback = false, inverse_image_analysis).
+// `argext(p, n, want_min)` is np.argmax / np.argmin; on the device it is a wave-cooperative search and every lane of
+// the wave runs this function with identical arguments.
+template <class AE>
+LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool fallback, int window, const AE& argext) {
+    TwoPeaks out;
+    out.n = 0;
+    if (n <= 0) return out;
+    const Peak a = analyze_peaks_at(p, n, argext(p, n, inverse), inverse, window);
+    out.n = 1; out.pk[0] = a; out.pk[1] = a;
+    const int s = a.start, e = a.end;
+    if (!(s > 1 && e < n - 2)) return out;
+    int left_len, right_off;
+    if (fallback) {
+        left_len = (s - rng > 0) ? py_head_len(s - rng, n) : py_head_len(s - 1, n);
+        right_off = (e + rng < n) ? (e + rng) : (e + 1);
+    } else {
+        left_len = py_head_len(s - rng, n);
+        right_off = e + rng;
+    }
+    if (right_off < 0) { right_off += n; if (right_off < 0) right_off = 0; }   // python p[k:] with negative k
+    if (right_off > n) right_off = n;
+    const int right_len = n - right_off;
+    if (!(left_len > 1 && right_len > 1)) return out;
+    const double* right = p + right_off;
+    const int il = argext(p, left_len, inverse);
+    const int ir = argext(right, right_len, inverse);
+    const bool take_left = inverse ? (right[ir] > p[il]) : (right[ir] < p[il]);
+    Peak b;
+    if (take_left) {
+        b = analyze_peaks_at(p, left_len, il, inverse, window);
+    } else {
+        b = analyze_peaks_at(right, right_len, ir, inverse, window);
+        b.start += e + rng;
+        b.end += e + rng;
+    }
+    const int s2 = b.start, e2 = b.end;
+    if ((s2 <= s && e2 > s) || (s2 <= e && e2 > e) || (s2 >= s && e2 <= e)) return out;
+    out.n = 2; out.pk[1] = b;
+    return out;
+}
+
+LFA_HD TwoPeaks two_peaks(const double* p, int n, bool inverse, int rng, bool fallback, int window) {
+    return two_peaks_t(p, n, inverse, rng, fallback, window, SeqArgExt());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// float Otsu on 256 bins (thresholding.py:364-381 with exposure.py:298-301): returns argmax index, writes centre
+// ---------------------------------------------------------------------------------------------------------------
+struct OtsuScratch { float w1[256]; float w2[256]; double m1[256]; double m2[256]; };
+
+LFA_HD int otsu_float256(const uint32_t* cnt, double vmin, double vmax, double* centre_out, OtsuScratch* ws) {
+    const int NB = 256;
+    const Linspace edges(vmin, vmax, NB + 1);
+    float* w1 = ws->w1; float* w2 = ws->w2;
+    double* m1 = ws->m1; double* m2 = ws->m2;
+    {
+        float acc = 0.0f;
+        for (int i = 0; i < NB; ++i) { acc = acc + (float)cnt[i]; w1[i] = acc; }
+        acc = 0.0f;
+        for (int i = NB - 1; i >= 0; --i) { acc = acc + (float)cnt[i]; w2[i] = acc; }
+        double s = 0.0;
+        for (int i = 0; i < NB; ++i) {
+            const double c = (edges(i) + edges(i + 1)) / 2.0;
+            s = s + (double)(float)cnt[i] * c;
+            m1[i] = s / (double)w1[i];
+        }
+        s = 0.0;
+        for (int i = NB - 1; i >= 0; --i) {
+            const double c = (edges(i) + edges(i + 1)) / 2.0;
+            s = s + (double)(float)cnt[i] * c;
+            m2[i] = s / (double)w2[i];
+        }
+    }
+    int best = 0;
+    double bv = 0.0;
+    for (int i = 0; i < NB - 1; ++i) {
+        const float ww = w1[i] * w2[i + 1];
+        const double d = m1[i] - m2[i + 1];
+        const double v = (double)ww * (d * d);
+        if (i == 0) { bv = v; best = 0; if (lfa_isnan(v)) break; }
+        else if (!(v <= bv)) { bv = v; best = i; if (lfa_isnan(v)) break; }
+    }
+    *centre_out = (edges(best) + edges(best + 1)) / 2.0;
+    return best;
+}
+
+}  // namespace lfa
+#endif  // LFA_ALGO_H_

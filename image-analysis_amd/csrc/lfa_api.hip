@@ -1,0 +1,356 @@
+// lfa_api.hip -- host side of the C ABI declared in include/lfa.h: handle, workspace, argument checks, launch order.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lfa_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define LFA_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) return fail(LFA_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));          \
+    } while (0)
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct LfaContext {
+    int device = 0;
+    int max_h = 0, max_w = 0, max_c = 0, max_batch = 0;
+    int gray_variant = LFA_GRAY_FMA_102;
+    Buf info, hist, edges, maskT, col_cnt, run_se, run_col, parent, area, bbox, firstbits, wordrank, root_of_label, cand,
+        cand_ok, lut8, lut16, rois;
+    lfa::Job last{};
+    bool have_last = false;
+    std::vector<Buf*> all() {
+        return {&info, &hist, &edges, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &firstbits, &wordrank,
+                &root_of_label, &cand, &cand_ok, &lut8, &lut16, &rois};
+    }
+};
+
+namespace {
+
+int ensure(Buf& b, size_t bytes) {
+    if (bytes <= b.bytes) return LFA_OK;
+    if (b.p) { LFA_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    bytes = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) return fail(LFA_ERR_NOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+    b.bytes = bytes;
+    return LFA_OK;
+}
+
+int run_capacity(int H, int W, int L) {
+    // interior runs are >= L long and separated by a gap; at most one shorter run at each border
+    const long long per_col = (long long)(H + 1) / (L + 1) + 2;
+    long long cap = per_col * W;
+    if (cap > 0x7fffffff) cap = 0x7fffffff;
+    return (int)cap;
+}
+
+// size every buffer for (n images of H x W, line_length L, dtype); grows only
+int ensure_workspace(LfaContext* h, int n, int H, int W, int dtype, int L, int max_strips) {
+    const size_t N = (size_t)n;
+    const int HB = (H + 63) / 64, W64 = (W + 63) / 64;
+    const size_t cap = (size_t)run_capacity(H, W, L);
+    const size_t hist_stride = (dtype == LFA_U16) ? lfa::kHistBinsU16 : 256;
+    int rc;
+    if ((rc = ensure(h->info, N * sizeof(LfaImageInfo)))) return rc;
+    if ((rc = ensure(h->hist, N * hist_stride * 4))) return rc;
+    if ((rc = ensure(h->edges, N * lfa::kEdges * 8))) return rc;
+    if ((rc = ensure(h->maskT, N * HB * W * 8))) return rc;
+    if ((rc = ensure(h->col_cnt, N * (W + 1) * 4))) return rc;
+    if ((rc = ensure(h->run_se, N * cap * 4))) return rc;
+    if ((rc = ensure(h->run_col, N * cap * 2))) return rc;
+    if ((rc = ensure(h->parent, N * cap * 4))) return rc;
+    if ((rc = ensure(h->area, N * cap * 4))) return rc;
+    if ((rc = ensure(h->bbox, N * cap * 16))) return rc;
+    if ((rc = ensure(h->firstbits, N * H * W64 * 8))) return rc;
+    if ((rc = ensure(h->wordrank, N * H * W64 * 4))) return rc;
+    if ((rc = ensure(h->root_of_label, N * cap * 4))) return rc;
+    if ((rc = ensure(h->cand, N * cap * 4))) return rc;
+    if ((rc = ensure(h->cand_ok, N * cap))) return rc;
+    if ((rc = ensure(h->rois, N * (size_t)max_strips * sizeof(LfaRoi)))) return rc;
+    return LFA_OK;
+}
+
+int check_images(LfaContext* h, const void* images, int dtype, int n, int H, int W, int C) {
+    if (!h) return fail(LFA_ERR_ARG, "null handle");
+    if (!images) return fail(LFA_ERR_ARG, "null image pointer");
+    if (dtype != LFA_U8 && dtype != LFA_U16) return fail(LFA_ERR_ARG, "dtype must be LFA_U8 or LFA_U16, got %d", dtype);
+    if (n < 1 || n > h->max_batch) return fail(LFA_ERR_ARG, "n=%d outside [1, max_batch=%d]", n, h->max_batch);
+    if (H < 1 || W < 1 || H > h->max_h || W > h->max_w) return fail(LFA_ERR_ARG, "image %dx%d outside the handle's %dx%d", H, W, h->max_h, h->max_w);
+    if (C != 1 && C != 3) return fail(LFA_ERR_ARG, "C must be 1 (2-D image) or 3 (colour), got %d (skimage rgb2gray: the input array must have size 3 along channel_axis)", C);
+    if (C > h->max_c) return fail(LFA_ERR_ARG, "C=%d exceeds the handle's max_c=%d", C, h->max_c);
+    return LFA_OK;
+}
+
+lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
+                  int L, int max_strips) {
+    lfa::Job j{};
+    j.images = (const uint8_t*)images;
+    j.img_bytes = (int64_t)H * W * C * (dtype == LFA_U16 ? 2 : 1);
+    j.n = n; j.H = H; j.W = W; j.C = C; j.dtype = dtype;
+    j.min_maxr = min_maxr; j.min_maxc = min_maxc; j.line_length = L;
+    j.gray_variant = h->gray_variant;
+    j.aligned16 = (((uintptr_t)images & 15) == 0 && (j.img_bytes & 15) == 0) ? 1 : 0;
+    j.HB = (H + 63) / 64; j.W64 = (W + 63) / 64;
+    j.run_cap = run_capacity(H, W, L);
+    j.max_strips = max_strips;
+    j.info = (LfaImageInfo*)h->info.p;
+    j.hist = (uint32_t*)h->hist.p;
+    j.hist_stride = (dtype == LFA_U16) ? lfa::kHistBinsU16 : 256;
+    j.edges_g = (double*)h->edges.p;
+    j.maskT = (uint64_t*)h->maskT.p;
+    j.col_cnt = (uint32_t*)h->col_cnt.p;
+    j.run_se = (uint32_t*)h->run_se.p;
+    j.run_col = (uint16_t*)h->run_col.p;
+    j.parent = (int32_t*)h->parent.p;
+    j.area = (int32_t*)h->area.p;
+    j.bbox = (int32_t*)h->bbox.p;
+    j.firstbits = (uint64_t*)h->firstbits.p;
+    j.wordrank = (uint32_t*)h->wordrank.p;
+    j.root_of_label = (int32_t*)h->root_of_label.p;
+    j.cand = (int32_t*)h->cand.p;
+    j.cand_ok = (uint8_t*)h->cand_ok.p;
+    j.lut8 = (const uint8_t*)h->lut8.p;
+    j.lut16 = (const uint16_t*)h->lut16.p;
+    return j;
+}
+
+int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
+                int L, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
+                LfaRoi* out_rois, hipStream_t s, lfa::Job* job_out) {
+    int rc = check_images(h, images, dtype, n, H, W, C);
+    if (rc) return rc;
+    if (C == 3 && dtype != LFA_U8) return fail(LFA_ERR_UNSUPPORTED, "colour images must be uint8 (uint16 colour is not implemented)");
+    if (H > 65535 || W > 65535) return fail(LFA_ERR_ARG, "image sides above 65535 are not supported");
+    if ((long long)H * W > (1ll << 24))
+        return fail(LFA_ERR_UNSUPPORTED, "images above 2^24 pixels are not supported: the reference's float32 histogram weights "
+                                         "(skimage thresholding.py:309) stop being exact there");
+    if (L < 1) return fail(LFA_ERR_ARG, "line_length must be >= 1");
+    if (min_maxr < 0 || min_maxc < 0) return fail(LFA_ERR_ARG, "min_maxr/min_maxc must be >= 0");
+    if (!out_strips || !out_counts) return fail(LFA_ERR_ARG, "null output pointer");
+    if (max_strips < 1 || max_strips > 1024) return fail(LFA_ERR_ARG, "max_strips must be in [1,1024]");
+    LFA_HIP(hipSetDevice(h->device));
+    if ((rc = ensure_workspace(h, n, H, W, dtype, L, max_strips))) return rc;
+    lfa::Job j = make_job(h, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
+    lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
+    LFA_HIP(lfa::launch_threshold(j, s));
+    LFA_HIP(lfa::launch_mask(j, s));
+    LFA_HIP(lfa::launch_label(j, s));
+    LFA_HIP(lfa::launch_regions(j, o, s));
+    h->last = j; h->have_last = true;
+    if (job_out) *job_out = j;
+    return LFA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lfa_version(void) { return LFA_VERSION; }
+
+const char* lfa_last_error(void) { return g_err.c_str(); }
+
+int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHandle* out) {
+    if (!out) return fail(LFA_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    if (max_h < 1 || max_w < 1 || max_batch < 1 || max_batch > 65535 || (max_c != 1 && max_c != 3))
+        return fail(LFA_ERR_ARG, "lfa_create: bad limits (max_h=%d max_w=%d max_c=%d max_batch=%d)", max_h, max_w, max_c, max_batch);
+    int ndev = 0;
+    LFA_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(LFA_ERR_ARG, "device %d not in [0,%d)", device, ndev);
+    LFA_HIP(hipSetDevice(device));
+    LfaContext* h = new (std::nothrow) LfaContext();
+    if (!h) return fail(LFA_ERR_NOMEM, "out of host memory");
+    h->device = device; h->max_h = max_h; h->max_w = max_w; h->max_c = max_c; h->max_batch = max_batch;
+    int rc;
+    if ((rc = ensure(h->lut8, 256)) || (rc = ensure(h->lut16, 65536 * 2))) { lfa_destroy(h); return rc; }
+    // default tables from the C library's pow(); the Python binding overrides them with numpy's
+    std::vector<uint8_t> l8(256);
+    for (int k = 0; k < 256; ++k) {
+        const double x = (k == 255) ? 1.0 : (double)k * (1.0 / 255.0) + 0.0;       // np.linspace(0, 1, 256)
+        double v = 255.0 * std::pow(x, 0.4);
+        v = std::nearbyint(v);
+        l8[k] = (uint8_t)(v < 255.0 ? v : 255.0);
+    }
+    std::vector<uint16_t> l16(65536);
+    for (int k = 0; k < 65536; ++k) l16[k] = (uint16_t)(std::pow((double)k / 65535.0, 0.4) * 65535.0 * 1);
+    if (hipMemcpy(h->lut8.p, l8.data(), 256, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->lut16.p, l16.data(), 65536 * 2, hipMemcpyHostToDevice) != hipSuccess) {
+        lfa_destroy(h);
+        return fail(LFA_ERR_HIP, "uploading gamma tables failed");
+    }
+    if ((rc = ensure_workspace(h, max_batch, max_h, max_w, LFA_U16, 10, 64))) { lfa_destroy(h); return rc; }
+    *out = h;
+    return LFA_OK;
+}
+
+int lfa_destroy(LfaHandle h) {
+    if (!h) return LFA_OK;
+    hipSetDevice(h->device);
+    for (Buf* b : h->all()) if (b->p) hipFree(b->p);
+    delete h;
+    return LFA_OK;
+}
+
+int lfa_set_gamma_lut(LfaHandle h, int dtype, const void* lut, int n) {
+    if (!h || !lut) return fail(LFA_ERR_ARG, "null argument");
+    LFA_HIP(hipSetDevice(h->device));
+    if (dtype == LFA_U8) {
+        if (n != 256) return fail(LFA_ERR_ARG, "uint8 table needs 256 entries, got %d", n);
+        const uint8_t* t = (const uint8_t*)lut;
+        for (int k = 1; k < 256; ++k) if (t[k] < t[k - 1]) return fail(LFA_ERR_ARG, "gamma table must be non-decreasing");
+        LFA_HIP(hipMemcpy(h->lut8.p, lut, 256, hipMemcpyHostToDevice));
+    } else if (dtype == LFA_U16) {
+        if (n != 65536) return fail(LFA_ERR_ARG, "uint16 table needs 65536 entries, got %d", n);
+        const uint16_t* t = (const uint16_t*)lut;
+        for (int k = 1; k < 65536; ++k) if (t[k] < t[k - 1]) return fail(LFA_ERR_ARG, "gamma table must be non-decreasing");
+        LFA_HIP(hipMemcpy(h->lut16.p, lut, 65536 * 2, hipMemcpyHostToDevice));
+    } else {
+        return fail(LFA_ERR_ARG, "bad dtype %d", dtype);
+    }
+    return LFA_OK;
+}
+
+int lfa_set_gray_variant(LfaHandle h, int variant) {
+    if (!h) return fail(LFA_ERR_ARG, "null handle");
+    if (variant < 0 || variant >= LFA_GRAY_NVARIANTS) return fail(LFA_ERR_ARG, "gray variant %d not in [0,%d)", variant, LFA_GRAY_NVARIANTS);
+    h->gray_variant = variant;
+    return LFA_OK;
+}
+
+int lfa_detect_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
+                     int line_length, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
+                     void* stream) {
+    return detect_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts,
+                       out_info, nullptr, (hipStream_t)stream, nullptr);
+}
+
+int lfa_profile_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, const LfaRoi* rois,
+                      int n_rois, int inverse, int range, double* out_profiles, int profile_stride, LfaPeaks* out_peaks,
+                      void* stream) {
+    int rc = check_images(h, images, dtype, n, H, W, C);
+    if (rc) return rc;
+    if (n_rois < 0) return fail(LFA_ERR_ARG, "n_rois < 0");
+    if (n_rois == 0) return LFA_OK;
+    if (!rois || !out_profiles || !out_peaks) return fail(LFA_ERR_ARG, "null pointer");
+    if (profile_stride < 1) return fail(LFA_ERR_ARG, "profile_stride must be >= 1");
+    LFA_HIP(hipSetDevice(h->device));
+    lfa::Job j{};
+    j.images = (const uint8_t*)images;
+    j.img_bytes = (int64_t)H * W * C * (dtype == LFA_U16 ? 2 : 1);
+    j.n = n; j.H = H; j.W = W; j.C = C; j.dtype = dtype;
+    LFA_HIP(lfa::launch_profiles(j, rois, n_rois, nullptr, 0, inverse, range, out_profiles, profile_stride, out_peaks,
+                                 (hipStream_t)stream));
+    return LFA_OK;
+}
+
+int lfa_peaks_batch(LfaHandle h, const double* profiles, const int32_t* lengths, int n_profiles, int profile_stride,
+                    int inverse, int window_size, int two_peaks, int range, LfaPeaks* out_peaks, void* stream) {
+    if (!h) return fail(LFA_ERR_ARG, "null handle");
+    if (n_profiles < 0) return fail(LFA_ERR_ARG, "n_profiles < 0");
+    if (n_profiles == 0) return LFA_OK;
+    if (!profiles || !lengths || !out_peaks) return fail(LFA_ERR_ARG, "null pointer");
+    if (profile_stride < 1 || window_size < 0) return fail(LFA_ERR_ARG, "bad stride / window");
+    LFA_HIP(hipSetDevice(h->device));
+    LFA_HIP(lfa::launch_peaks(profiles, lengths, n_profiles, profile_stride, inverse, window_size, two_peaks, range,
+                              out_peaks, (hipStream_t)stream));
+    return LFA_OK;
+}
+
+int lfa_analyze_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
+                      int line_length, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
+                      LfaRoi* out_rois, double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream) {
+    if (!out_profiles || !out_peaks) return fail(LFA_ERR_ARG, "null output pointer");
+    if (profile_stride < 1) return fail(LFA_ERR_ARG, "profile_stride must be >= 1");
+    lfa::Job j{};
+    // rois go to the caller's buffer or to the handle's own
+    int rc = check_images(h, images, dtype, n, H, W, C);
+    if (rc) return rc;
+    if (max_strips < 1 || max_strips > 1024) return fail(LFA_ERR_ARG, "max_strips must be in [1,1024]");
+    LFA_HIP(hipSetDevice(h->device));
+    if (!out_rois) {
+        if ((rc = ensure(h->rois, (size_t)n * max_strips * sizeof(LfaRoi)))) return rc;
+        out_rois = (LfaRoi*)h->rois.p;
+    }
+    rc = detect_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts,
+                     out_info, out_rois, (hipStream_t)stream, &j);
+    if (rc) return rc;
+    LFA_HIP(lfa::launch_profiles(j, out_rois, n * max_strips, out_counts, max_strips, 0, 15, out_profiles, profile_stride,
+                                 out_peaks, (hipStream_t)stream));
+    return LFA_OK;
+}
+
+int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, double sigma,
+                       const double* host_weights, int radius, void* out, int out_f32, void* stream) {
+    int rc = check_images(h, images, dtype, n, H, W, C);
+    if (rc) return rc;
+    if (!out) return fail(LFA_ERR_ARG, "null output pointer");
+    double w[2 * lfa::kGaussMaxRadius + 1];
+    if (host_weights) {
+        if (radius < 0 || radius > lfa::kGaussMaxRadius) return fail(LFA_ERR_UNSUPPORTED, "radius %d outside [0,%d]", radius, lfa::kGaussMaxRadius);
+        for (int k = 0; k < 2 * radius + 1; ++k) w[k] = host_weights[k];
+    } else {
+        if (!(sigma > 0.0)) return fail(LFA_ERR_ARG, "sigma must be > 0");
+        radius = (int)(4.0 * sigma + 0.5);
+        if (radius > lfa::kGaussMaxRadius) return fail(LFA_ERR_UNSUPPORTED, "sigma %.3f needs radius %d > %d", sigma, radius, lfa::kGaussMaxRadius);
+        // scipy.ndimage._filters._gaussian_kernel1d: exp(-0.5 / sigma^2 * x^2), normalised by the plain sum
+        const double sigma2 = sigma * sigma;
+        double sum = 0.0;
+        for (int k = -radius; k <= radius; ++k) { w[k + radius] = std::exp(-0.5 / sigma2 * (double)(k * k)); }
+        for (int k = 0; k < 2 * radius + 1; ++k) sum += w[k];
+        for (int k = 0; k < 2 * radius + 1; ++k) w[k] /= sum;
+    }
+    LFA_HIP(hipSetDevice(h->device));
+    lfa::Job j{};
+    j.images = (const uint8_t*)images;
+    j.img_bytes = (int64_t)H * W * C * (dtype == LFA_U16 ? 2 : 1);
+    j.n = n; j.H = H; j.W = W; j.C = C; j.dtype = dtype;
+    LFA_HIP(lfa::launch_gaussian_w(j, w, radius, out, out_f32, (hipStream_t)stream));
+    return LFA_OK;
+}
+
+int lfa_debug_fetch(LfaHandle h, int image_index, int what, void* out, int64_t out_bytes, void* stream) {
+    if (!h || !out) return fail(LFA_ERR_ARG, "null argument");
+    if (!h->have_last) return fail(LFA_ERR_ARG, "no detect/analyze call has run on this handle yet");
+    if (image_index < 0 || image_index >= h->last.n) return fail(LFA_ERR_ARG, "image_index %d outside the last batch of %d", image_index, h->last.n);
+    LFA_HIP(hipSetDevice(h->device));
+    hipError_t e = lfa::launch_debug(h->last, image_index, what, out, out_bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? LFA_ERR_ARG : LFA_ERR_HIP, "lfa_debug_fetch(what=%d): %s", what, hipGetErrorString(e));
+    return LFA_OK;
+}
+
+int lfa_sync(LfaHandle h, void* stream) {
+    if (!h) return fail(LFA_ERR_ARG, "null handle");
+    LFA_HIP(hipSetDevice(h->device));
+    LFA_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return LFA_OK;
+}
+
+}  // extern "C"

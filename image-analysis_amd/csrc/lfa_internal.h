@@ -1,0 +1,75 @@
+// lfa_internal.h -- workspace layout and kernel launchers shared by the translation units of liblfa_hip.so
+#ifndef LFA_INTERNAL_H_
+#define LFA_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lfa.h"
+
+namespace lfa {
+
+constexpr int kHistBinsU16 = 65536;
+constexpr int kEdges = 257;              // 256 float bins -> 257 edges
+constexpr int kAreaMin = 100;            // detection.py:81
+constexpr int kMaxCand = 1 << 20;
+
+// Device-side description of one batch call.  Passed BY VALUE to every kernel (fits the kernarg segment).
+struct Job {
+    // input
+    const uint8_t* images;   // batch-major
+    int64_t img_bytes;       // bytes per image
+    int32_t n, H, W, C;
+    int32_t dtype;           // LFA_U8 / LFA_U16
+    int32_t min_maxr, min_maxc, line_length;
+    int32_t gray_variant;
+    int32_t aligned16;       // images base and per-image / per-row strides allow 16-byte vector loads
+    // derived
+    int32_t HB;              // row blocks of 64 rows
+    int32_t W64;             // 64-column words per row of the first-pixel bitmap
+    int32_t run_cap;         // run capacity per image
+    int32_t max_strips;
+    // workspace (all per image, image i at i*stride)
+    LfaImageInfo* info;      // [n]
+    uint32_t* hist;          // [n][65536]      (uint16)  or [n][256]
+    int32_t hist_stride;
+    double* edges_g;         // [n][257]  gray-space bin edges (colour path)
+    uint64_t* maskT;         // [n][HB][W]      vertical 64-row words, thresholded image
+    uint32_t* col_cnt;       // [n][W+1]        runs per column -> exclusive offsets
+    uint32_t* run_se;        // [n][run_cap]    start | (end_inclusive << 16)
+    uint16_t* run_col;       // [n][run_cap]
+    int32_t* parent;         // [n][run_cap]
+    int32_t* area;           // [n][run_cap]    valid at roots
+    int32_t* bbox;           // [n][run_cap][4] minr, minc, maxr, maxc (half-open) valid at roots
+    uint64_t* firstbits;     // [n][H*W64]      bit set at the raster-first pixel of every component
+    uint32_t* wordrank;      // [n][H*W64]      exclusive prefix popcount of firstbits
+    int32_t* root_of_label;  // [n][run_cap]
+    int32_t* cand;           // [n][run_cap]    labels (1-based) with area >= 100, ascending
+    uint8_t* cand_ok;        // [n][run_cap]    mean test passed
+    const uint8_t* lut8;     // [256]
+    const uint16_t* lut16;   // [65536]
+};
+
+struct OutPtrs {
+    LfaStrip* strips;        // [n][max_strips]
+    int32_t* counts;         // [n]
+    LfaImageInfo* info;      // [n] or null
+    LfaRoi* rois;            // [n][max_strips] or null
+};
+
+// --- launchers (each enqueues on `s` and returns the launch status) -----------------------------------------------
+hipError_t launch_threshold(const Job& j, hipStream_t s);                 // min/max, histogram, Otsu -> info
+hipError_t launch_mask(const Job& j, hipStream_t s);                      // thresholded image -> maskT
+hipError_t launch_label(const Job& j, hipStream_t s);                     // opening + runs + union-find + ranks
+hipError_t launch_regions(const Job& j, const OutPtrs& o, hipStream_t s); // candidates, box means, accept, sort
+hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const int32_t* counts_or_null,
+                           int max_strips_or_0, int inverse, int rng, double* profiles, int stride, LfaPeaks* peaks,
+                           hipStream_t s);
+hipError_t launch_peaks(const double* profiles, const int32_t* lengths, int n, int stride, int inverse, int window,
+                        int two, int rng, LfaPeaks* out, hipStream_t s);
+hipError_t launch_gaussian_w(const Job& j, const double* w, int radius, void* out, int out_f32, hipStream_t s);
+constexpr int kGaussMaxRadius = 8;
+hipError_t launch_debug(const Job& j, int image, int what, void* out, int64_t out_bytes, hipStream_t s);
+
+}  // namespace lfa
+#endif

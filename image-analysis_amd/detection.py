@@ -1,0 +1,195 @@
+"""Drop-in for the hot path of the reference's LFA-Image_Analysis/detection.py (functions at :31-316).
+
+Same names, signatures, defaults, module globals, return types and exceptions; the GUI class (:319-789) is not
+part of this module and importing it opens no window.  Every numeric step runs in liblfa_hip.so on the MI355X
+(through image-analysis_amd/_capi.py); this module only marshals arrays and keeps the reference's host-side list
+logic.  There is no CPU fallback: without the HIP library or without a GPU the calls raise.
+
+    import image_analysis_amd.detection as detection
+    detection.min_maxc = int(width / 40); detection.min_maxr = int(detection.min_maxc * 20)   # detection.py:457-460
+    crops = detection.detect_lateral_flow_tests(image)                                         # detection.py:462
+    profile, peaks = detection.image_analysis(crops[0], False)                                 # detection.py:543
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi
+
+# module globals the reference's callers assign with `global` (detection.py:25-28)
+image_obj = None
+min_maxr, min_maxc = 0, 0
+angle_threshold = 0
+file_path = ""
+
+_DEVICE = 0
+
+
+def set_device(index: int) -> None:
+    """Select the GPU the module-level functions run on (new; the reference has no devices)."""
+    global _DEVICE
+    _DEVICE = int(index)
+
+
+def _engine(H, W):
+    return _capi.shared_engine(_DEVICE, H, W)
+
+
+def _check_pixels(image: np.ndarray) -> np.ndarray:
+    if image.dtype == np.uint8 or image.dtype == np.uint16:
+        return image
+    if image.dtype.kind in "if" and np.any(image < 0):
+        # skimage.exposure._assert_non_negative (exposure.py:603-608)
+        raise ValueError("Image Correction methods work correctly only on images with non-negative values. "
+                         "Use skimage.exposure.rescale_intensity.")
+    raise NotImplementedError(f"pixel dtype {image.dtype}: the HIP path takes uint8 and uint16 images "
+                              "(what cv2.imread / tifffile hand the reference, detection.py:454)")
+
+
+def detect_lateral_flow_tests(image, line_length=10):
+    """detection.py:31-94.  Returns views `image[minr:maxr, minc:maxc]` sorted by (minc, maxc)."""
+    image = np.asanyarray(image)
+    if image.ndim == 2:
+        pass
+    elif image.ndim == 3:
+        if image.shape[-1] != 3:
+            # skimage.color.colorconv._prepare_colorarray (colorconv.py:137-140)
+            raise ValueError(f"the input array must have size 3 along `channel_axis`, got {image.shape}")
+    else:
+        raise ValueError("Invalid image dimensions. Only 2D and 3D images are supported.")
+    if image.size == 0:
+        raise ValueError("empty image")
+    _check_pixels(image)
+    H, W = image.shape[0], image.shape[1]
+    eng = _engine(H, W)
+    strips, _info = eng.detect(image[None], int(min_maxr), int(min_maxc), int(line_length))
+    return [image[int(s["minr"]):int(s["maxr"]), int(s["minc"]):int(s["maxc"])] for s in strips[0]]
+
+
+def straighten_region(copy_image, region, angles):
+    """detection.py:97-115 rotates a patch of a private copy that is never read again (:69, :86): no effect on any
+    result, so nothing is computed here."""
+    return None
+
+
+def check_duplicate(minr, minc, maxr, maxc, lst) -> bool:
+    """detection.py:118-127 (host list logic; the batched path runs the same test on the device)."""
+    for region in lst:
+        cur_minr, cur_maxr, cur_minc, cur_maxc = region[0], region[1], region[2], region[3]
+        cur_maxr = max(cur_maxr, cur_minr + min_maxr)
+        cur_maxc = max(cur_maxc, cur_minc + min_maxc)
+        if minr <= cur_maxr and maxr >= cur_minr and minc <= cur_maxc and maxc >= cur_minc:
+            return False
+    return True
+
+
+def remove_outliers(lst):
+    """detection.py:138-153."""
+    widths = [max(r[3], r[2] + min_maxc) - r[2] for r in lst]
+    if not widths:
+        return []
+    narrowest = min(widths)
+    return [r for r, w in zip(lst, widths) if w <= narrowest * 2]
+
+
+def detect_lines(image) -> list:
+    """detection.py:156-201 is never called by the reference; only its Gaussian stage is built
+    (see `gaussian`)."""
+    raise NotImplementedError("detect_lines is dead code in the reference; only its gaussian stage is implemented")
+
+
+def gaussian(image, sigma=1):
+    """skimage.filters.gaussian(image, sigma) as detect_lines calls it (detection.py:166): float64 result."""
+    image = np.asanyarray(image)
+    _check_pixels(image)
+    if image.ndim == 3 and image.shape[-1] != 3:
+        raise NotImplementedError("only (H,W) and (H,W,3) images")
+    eng = _engine(image.shape[0], image.shape[1])
+    return eng.gaussian(image[None], sigma=float(sigma))[0]
+
+
+def _as_2d_elements(region: np.ndarray):
+    """(h,w) or (h,w,c) -> contiguous (h, w*c) plus c: the row mean over columns and channels is the mean over w*c elements."""
+    if region.ndim == 3:
+        h, w, c = region.shape
+        return np.ascontiguousarray(region).reshape(h, w * c), c
+    if region.ndim == 2:
+        return np.ascontiguousarray(region), 1
+    raise ValueError(f"not enough values to unpack (expected 2, got {region.ndim})")
+
+
+def _peaks_to_list(pk):
+    out = []
+    for i in range(int(pk["n_peaks"])):
+        out.append((int(pk["start"][i]), int(pk["end"][i]), np.float64(pk["area"][i])))
+    return out
+
+
+def _analysis(region, selected, rng, inverse):
+    region = np.asanyarray(region)
+    _check_pixels(region)
+    flat, c = _as_2d_elements(region)
+    h, we = flat.shape
+    w = we // c
+    if selected:
+        r0, r1, c0, c1 = 0, h, 0, w
+    else:
+        r0, r1, c0, c1 = int(h * .25), int(h * .6), int(w * .3), int(w * .7)
+    if r1 - r0 <= 0:
+        raise ValueError("attempt to get argmax of an empty sequence" if not inverse else
+                         "attempt to get argmin of an empty sequence")
+    if h == 0 or we == 0:
+        raise ValueError("attempt to get argmax of an empty sequence")
+    roi = np.zeros(1, dtype=_capi.ROI_DT)
+    roi["image"], roi["r0"], roi["r1"], roi["c0"], roi["c1"] = 0, r0, r1, c0 * c, c1 * c
+    eng = _engine(h, we)
+    profiles, peaks = eng.profiles(flat[None], roi, inverse=inverse, rng=int(rng))
+    return [profiles[0], _peaks_to_list(peaks[0])]
+
+
+def image_analysis(region, selected, range=15):
+    """detection.py:205-245 -> [profile float64 (h',), [(start, end, area)[, (start2, end2, area2)]]]."""
+    return _analysis(region, selected, range, inverse=False)
+
+
+def inverse_image_analysis(region, selected, range=1):
+    """detection.py:247-281 (valleys).  Like the reference it needs a 3-D region (:249)."""
+    region = np.asanyarray(region)
+    if region.ndim != 3:
+        raise ValueError(f"not enough values to unpack (expected 3, got {region.ndim})")
+    return _analysis(region, selected, range, inverse=True)
+
+
+def analyze_peaks(profile, inverse=False, window_size=25):
+    """detection.py:283-316 -> (start_index, end_index, area)."""
+    profile = np.ascontiguousarray(profile, dtype=np.float64)
+    if profile.ndim != 1:
+        raise ValueError("profile must be one-dimensional")
+    if profile.size == 0:
+        raise ValueError("attempt to get argmax of an empty sequence")
+    pk = _capi.shared_engine(_DEVICE).peaks([profile], inverse=inverse, window_size=int(window_size))[0]
+    return int(pk["start"][0]), int(pk["end"][0]), np.float64(pk["area"][0])
+
+
+# ---- batch entry points (new: SURVEY.md section 3.4; the reference handles one image and one strip at a time) --------
+def analyze_batch(images, line_length=10, max_batch=16, device=None):
+    """detect + image_analysis(strip, False) for every strip of every image of a (n,H,W[,3]) batch.
+
+    Uses the module globals min_maxr / min_maxc exactly like detect_lateral_flow_tests.  Returns one entry per image:
+    a list of (crop_view, profile, peaks) in the order detect_lateral_flow_tests returns the crops."""
+    images = np.asanyarray(images)
+    if images.ndim not in (3, 4) or (images.ndim == 4 and images.shape[-1] != 3):
+        raise ValueError("expected a batch (n,H,W) or (n,H,W,3)")
+    _check_pixels(images)
+    dev = _DEVICE if device is None else int(device)
+    eng = _capi.Engine(device=dev, max_h=images.shape[1], max_w=images.shape[2], max_c=3, max_batch=max_batch)
+    try:
+        res, _info = eng.analyze(images, int(min_maxr), int(min_maxc), int(line_length))
+    finally:
+        eng.close()
+    out = []
+    for i, (strips, profiles, peaks) in enumerate(res):
+        img = images[i]
+        out.append([(img[int(s["minr"]):int(s["maxr"]), int(s["minc"]):int(s["maxc"])], profiles[k], _peaks_to_list(peaks[k]))
+                    for k, s in enumerate(strips)])
+    return out

@@ -1,0 +1,196 @@
+/*
+ * lfa.h -- C ABI of the MI355X-native LFA (lateral-flow-assay) analysis hot path.
+ *
+ * The reference (bwasden2003/Image-Analysis) has no FFI layer: its boundary for this path is the set of
+ * module-level Python functions in LFA-Image_Analysis/detection.py that the GUI calls.  This header is what
+ * a binding for those functions talks to (ctypes stub: image-analysis_amd/_capi.py, and INTEGRATION.md).
+ * Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every call returns 0 on success or a negative LFA_ERR_* code,
+ *     lfa_last_error() returns a thread-local message for the last failing call on this thread;
+ *   - image / ROI / output pointers are DEVICE pointers (hipMalloc memory, e.g. torch.Tensor.data_ptr())
+ *     unless a parameter is documented as host memory; images are C-contiguous, batch-major:
+ *     image i starts at byte i * H*W*C*sizeof(pixel);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls enqueue work and
+ *     return without waiting unless documented otherwise; one handle per device and per host thread;
+ *   - nothing here reads or writes host memory behind the caller's back except the documented
+ *     host-pointer parameters.
+ */
+#ifndef LFA_H_
+#define LFA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFA_VERSION 1
+
+/* pixel types */
+#define LFA_U8  0
+#define LFA_U16 1
+
+/* error codes */
+#define LFA_OK               0
+#define LFA_ERR_ARG         -1   /* bad argument (shape, dtype, null pointer, size beyond the handle's limits) */
+#define LFA_ERR_HIP         -2   /* a HIP runtime call failed; message holds hipGetErrorString */
+#define LFA_ERR_UNSUPPORTED -3   /* valid in the reference but not implemented here (documented in DESIGN.md) */
+#define LFA_ERR_NOMEM       -4
+
+/* which rounding order `rgb @ [0.2125, 0.7154, 0.0721]` has on the host whose numpy is the yardstick
+ * (skimage/color/colorconv.py:876-877; the order is a property of the host BLAS, SURVEY.md section 7 hard part 1).
+ * x_k = fl(pixel_k * fl(1/255)); c = coefficients. */
+#define LFA_GRAY_FMA_102   0     /* fma(x2,c2, fma(x0,c0, x1*c1))   -- numpy 2.2.6 / OpenBLAS, x86-64 (probed) */
+#define LFA_GRAY_SEQ       1     /* (x0*c0 + x1*c1) + x2*c2 */
+#define LFA_GRAY_FMA_012   2     /* fma(x2,c2, fma(x1,c1, x0*c0)) */
+#define LFA_GRAY_FMA_210   3     /* fma(x0,c0, fma(x1,c1, x2*c2)) */
+#define LFA_GRAY_PAIR      4     /* x0*c0 + (x1*c1 + x2*c2) */
+#define LFA_GRAY_FMA01_ADD 5     /* fma(x1,c1, x0*c0) + x2*c2 */
+#define LFA_GRAY_NVARIANTS 6
+
+typedef struct LfaContext* LfaHandle;
+
+/* One accepted strip = one element of the list detect_lateral_flow_tests returns (detection.py:85-93).
+ * Coordinates are the reference's [minr, maxr, minc, maxc] AFTER the min_maxr/min_maxc expansion
+ * (detection.py:74) and BEFORE numpy's slice clipping, i.e. maxr/maxc may exceed H/W; crop = image[minr:maxr, minc:maxc]. */
+typedef struct {
+    int32_t minr, maxr, minc, maxc;
+    int32_t area;      /* regionprops area of the component (pixel count), detection.py:81 */
+    int32_t label;     /* its label id (1-based, scipy.ndimage.label numbering) */
+} LfaStrip;
+
+/* A rectangle of rows/cols of image `image` whose row-mean profile is wanted: rows [r0,r1), cols [c0,c1),
+ * already clipped to the image.  Equals the window image_analysis takes (detection.py:215-218). */
+typedef struct {
+    int32_t image;
+    int32_t r0, r1, c0, c1;
+} LfaRoi;
+
+/* Result of image_analysis / inverse_image_analysis for one ROI (detection.py:241-245, :277-281). */
+typedef struct {
+    int32_t n_peaks;        /* 0 (empty profile: the reference raises ValueError), 1 or 2 */
+    int32_t length;         /* profile length = r1 - r0 */
+    int32_t start[2];
+    int32_t end[2];
+    double  area[2];
+} LfaPeaks;
+
+/* Per-image intermediates of the detect path, for parity checks and diagnostics. */
+typedef struct {
+    /* integer path (2-D uint8 / uint16): everything in integers */
+    int32_t xmin, xmax;       /* min / max pixel value */
+    int32_t v_thr;            /* threshold_otsu(adjust_gamma(image, 0.4)) -- the reference's `threshold` (detection.py:38) */
+    int32_t x_thr;            /* mask == (pixel > x_thr): largest input value whose gamma value is <= v_thr */
+    /* colour path ((H,W,3) uint8): gray is float64 */
+    double  gmin, gmax;       /* min / max of rgb2gray(image) */
+    double  vmin, vmax;       /* pow(gmin,0.4), pow(gmax,0.4) evaluated on the device */
+    double  v_thr_f;          /* bin centre chosen by Otsu, from the device's vmin/vmax */
+    double  g_thr;            /* mask == (gray > g_thr) */
+    int32_t otsu_bin;         /* argmax index into variance12 (thresholding.py:378) */
+    int32_t all_equal;        /* 1: every gamma value identical -> threshold = that value, empty mask (thresholding.py:359-362) */
+    uint32_t ambiguous;       /* colour path: pixels closer than 2^-40 (relative) to a histogram edge or to the threshold,
+                                 i.e. pixels whose side could depend on the last bits of the host's pow(); 0 in practice */
+    /* labelling */
+    int32_t n_runs;           /* vertical runs that survive the opening */
+    int32_t n_labels;         /* K of label() (detection.py:66) */
+    int32_t label00;          /* labeled[0,0] -- the reference's `background_color` (detection.py:67) */
+    int32_t n_candidates;     /* labels with area >= 100 */
+    int32_t n_accepted;       /* after the mean test and check_duplicate (detection.py:81-85) */
+    int32_t n_strips;         /* after remove_outliers (detection.py:87); may exceed max_strips -> see status */
+    int32_t status;           /* 0 ok; bit0: n_strips/n_accepted exceeded max_strips (outputs truncated);
+                                 bit1: run capacity exceeded */
+} LfaImageInfo;
+
+/* ---- lifetime ---------------------------------------------------------------------------------------------------- */
+
+/* Create a context on `device`.  max_h/max_w/max_c bound the images later calls may pass; max_batch bounds n per call.
+ * Allocates all device workspace here (no allocation happens in the enqueue calls unless a later call exceeds these
+ * limits, which is an error).  Builds the default gamma LUTs with the C library's pow().
+ * Replaces: module import + the three globals of detection.py:25-28 (state lives in the handle instead). */
+int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHandle* out);
+int lfa_destroy(LfaHandle h);
+const char* lfa_last_error(void);
+int lfa_version(void);
+
+/* Gamma look-up tables of skimage.exposure.adjust_gamma(image, 0.4) (exposure.py:611-617 for uint8, :674-679 for
+ * uint16).  `lut` is HOST memory: 256 uint8 or 65536 uint16 values, must be non-decreasing.  The Python binding passes
+ * tables built with the host's numpy so that they carry that numpy's pow() bits. */
+int lfa_set_gamma_lut(LfaHandle h, int dtype, const void* lut, int n);
+
+/* Select the rounding order of rgb2gray's matmul (LFA_GRAY_*), colorconv.py:876-877. */
+int lfa_set_gray_variant(LfaHandle h, int variant);
+
+/* ---- detect: detect_lateral_flow_tests(image, line_length) -- detection.py:31-94 ----------------------------------- */
+
+/* images: n images of H x W x C pixels of `dtype` (C==1: 2-D input; C==3: colour, uint8 only).
+ * min_maxr/min_maxc: the module globals of detection.py:26 the GUI sets at :457-460.
+ * out_strips: device, n * max_strips records; image i's strips start at i*max_strips, sorted by (minc, maxc) (detection.py:89).
+ * out_counts: device, n int32 = number of strips of image i (<= max_strips unless info.status bit0).
+ * out_info:   device, n LfaImageInfo, or NULL.
+ * The canny / Hough / rotate stages (detection.py:51-57, :84) do not influence the return value and are not run. */
+int lfa_detect_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C,
+                     int min_maxr, int min_maxc, int line_length,
+                     LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
+                     void* stream);
+
+/* ---- profile + peaks: image_analysis / inverse_image_analysis / analyze_peaks -- detection.py:205-316 ------------- */
+
+/* For each ROI: profile[k] = mean over cols [c0,c1) and channels of row r0+k (np.nanmean of an integer array,
+ * detection.py:219), then the one- or two-peak logic (detection.py:221-245; `inverse` != 0: :257-281).
+ * `range` is the reference's parameter of the same name (15 for image_analysis, 1 for inverse_image_analysis).
+ * rois: device, n_rois records.  out_profiles: device, n_rois * profile_stride float64; ROI j's profile starts at
+ * j*profile_stride; every ROI must have r1-r0 <= profile_stride (else LFA_ERR_ARG is reported through out_peaks[j].n_peaks = -1).
+ * out_peaks: device, n_rois records. */
+int lfa_profile_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C,
+                      const LfaRoi* rois, int n_rois, int inverse, int range,
+                      double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream);
+
+/* analyze_peaks(profile, inverse, window_size) on caller-supplied float64 profiles (detection.py:283-316).
+ * profiles: device, n_profiles * profile_stride float64; lengths: device int32[n_profiles].
+ * out: device LfaPeaks[n_profiles] with n_peaks = 1 (start[0], end[0], area[0]); when `two_peaks` != 0 the full
+ * image_analysis peak logic (detection.py:221-245 / :257-281) runs instead, with `range`. */
+int lfa_peaks_batch(LfaHandle h, const double* profiles, const int32_t* lengths, int n_profiles, int profile_stride,
+                    int inverse, int window_size, int two_peaks, int range, LfaPeaks* out_peaks, void* stream);
+
+/* ---- the whole job: detect, then image_analysis(strip, selected=False) of every strip ----------------------------- */
+
+/* = for image in batch: for strip in detect_lateral_flow_tests(image): image_analysis(strip, False)
+ *   (GUI sequence detection.py:462 then :543 with default gamma/exposure), with no host round trip.
+ * out_rois (device, n*max_strips, may be NULL) receives the window of each strip (detection.py:216);
+ * out_profiles: device, n*max_strips*profile_stride float64; out_peaks: device, n*max_strips.
+ * Slots beyond out_counts[i] are left untouched. */
+int lfa_analyze_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C,
+                      int min_maxr, int min_maxc, int line_length,
+                      LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
+                      LfaRoi* out_rois, double* out_profiles, int profile_stride, LfaPeaks* out_peaks,
+                      void* stream);
+
+/* ---- gaussian: skimage.filters.gaussian(image, sigma) -- skimage/_shared/filters.py:35-166, caller detection.py:166 ---- */
+
+/* Separable Gaussian, mode='nearest', truncate=4.0, on img_as_float(image) (uint8: x*(1/255), uint16: x*(1/65535)),
+ * axis 0 then axis 1, channels (C==3) filtered independently.  out: device, n*H*W*C float64 (out_f32 == 0) or float32.
+ * host_weights: HOST memory, 2*radius+1 kernel taps as scipy.ndimage._filters._gaussian_kernel1d builds them, or NULL
+ * to have them computed here from sigma with the C library's exp() (radius = int(4*sigma + 0.5), at most 8). */
+int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C,
+                       double sigma, const double* host_weights, int radius, void* out, int out_f32, void* stream);
+
+/* ---- diagnostics for parity tests (valid until the next detect/analyze call on this handle) ----------------------- */
+
+#define LFA_DBG_MASK    0   /* uint8 H*W : image_copy > threshold            (detection.py:39,47) */
+#define LFA_DBG_OPENED  1   /* uint8 H*W : binary_dilation(binary_erosion())  (detection.py:60-63) */
+#define LFA_DBG_LABELS  2   /* int32 H*W : label(dilated)                     (detection.py:66) */
+#define LFA_DBG_TABLE   3   /* int32 K*5 : minr,minc,maxr,maxc,area per label (regionprops, detection.py:71-73) */
+#define LFA_DBG_HIST    4   /* uint32 nb : histogram counts (nb = 256 colour / uint8, xmax-xmin+1 uint16; input domain) */
+
+/* Rasterise intermediate `what` of image `image_index` of the LAST detect/analyze call into `out` (device). */
+int lfa_debug_fetch(LfaHandle h, int image_index, int what, void* out, int64_t out_bytes, void* stream);
+
+/* Block until everything enqueued on `stream` through this handle has finished. */
+int lfa_sync(LfaHandle h, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFA_H_ */

@@ -1,0 +1,206 @@
+"""GPU parity of the detect path against the oracle, through the C ABI (liblfa_hip.so via ctypes).
+
+Bar: bit-exact Otsu threshold, mask, opened mask, label image, bbox/area table, accepted strips and crops."""
+import os
+
+import numpy as np
+import pytest
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lfa_oracle as O
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import image_analysis_amd._capi as capi
+    return capi
+
+
+@pytest.fixture(scope="module")
+def eng(capi):
+    e = capi.Engine(device=0, max_h=2048, max_w=2048, max_c=3, max_batch=8)
+    yield e
+    e.close()
+
+
+def gui_params(image):
+    mm_c = int(image.shape[1] / 40)        # detection.py:457-460
+    return int(mm_c * 20), mm_c
+
+
+def check_detect(capi, eng, image, mm_r, mm_c, L=10, batch_index=0, res=None):
+    d = O.detect_debug(image, mm_r, mm_c, L)
+    if res is None:
+        strips, info = eng.detect(image[None], mm_r, mm_c, L)
+    else:
+        strips, info = res
+    H, W = image.shape[:2]
+    inf = info[batch_index]
+    colour = image.ndim == 3
+    assert inf["status"] == 0
+    assert inf["ambiguous"] == 0
+    thr = capi.host_threshold(inf, colour)
+    assert thr == d["threshold"], (thr, d["threshold"])
+    mask = eng.debug(batch_index, capi.DBG_MASK, H, W).astype(bool)
+    assert np.array_equal(mask, d["mask"])
+    opened = eng.debug(batch_index, capi.DBG_OPENED, H, W).astype(bool)
+    assert np.array_equal(opened, d["opened"])
+    labels = eng.debug(batch_index, capi.DBG_LABELS, H, W)
+    assert labels.dtype == np.int32
+    assert np.array_equal(labels, d["labels"])
+    assert inf["n_labels"] == d["n_labels"]
+    assert inf["label00"] == int(d["background"])
+    table = eng.debug_table(batch_index, d["n_labels"])
+    assert np.array_equal(table.astype(np.int64), d["table"])
+    got = [[int(s["minr"]), int(s["maxr"]), int(s["minc"]), int(s["maxc"])] for s in strips[batch_index]]
+    assert got == d["strips"]
+    assert [int(s["label"]) for s in strips[batch_index]] == d["strip_labels"]
+    assert [int(s["area"]) for s in strips[batch_index]] == d["strip_areas"]
+    assert inf["n_accepted"] == len(d["accepted"])
+    return d
+
+
+def test_excel2_frame_uint16(capi, eng, golden_dir):
+    frame = np.array(Image.open(os.path.join(golden_dir, "excel2_frame.png")))
+    mm_r, mm_c = gui_params(frame)
+    d = check_detect(capi, eng, frame, mm_r, mm_c)
+    assert d["threshold"] == 5086 and d["n_labels"] == 1149 and len(d["strips"]) == 40
+    assert [324, 1344, 806, 857] in d["strips"]            # the crop the reference exported (images/excel2.xlsx)
+
+
+def test_image1_gray_and_bgr(capi, eng, golden_dir):
+    g = np.load(os.path.join(golden_dir, "image1_decoded.npz"))["gray"]
+    mm_r, mm_c = gui_params(g)
+    check_detect(capi, eng, g, mm_r, mm_c)
+    bgr = np.repeat(g[:, :, None], 3, axis=2)               # what cv2.imread returns for a grayscale JPEG
+    check_detect(capi, eng, bgr, mm_r, mm_c)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_synthetic_rgb(capi, eng, seed):
+    from image_analysis_amd.synth import synth_rgb
+    img = synth_rgb(384, 512, 8, seed)
+    mm_r, mm_c = gui_params(img)
+    d = check_detect(capi, eng, img, mm_r, mm_c)
+    assert len(d["strips"]) >= 4
+
+
+def test_synthetic_u16_small(capi, eng):
+    from image_analysis_amd.synth import synth_u16
+    img = synth_u16(512, 512, 10, 5)
+    mm_r, mm_c = gui_params(img)
+    check_detect(capi, eng, img, mm_r, mm_c)
+
+
+def test_full_range_uint16(capi, eng):
+    rng = np.random.default_rng(11)
+    img = (rng.random((256, 320)) * 65535).astype(np.uint16)
+    img[40:200, 50:80] = 60000
+    img[0, 0] = 0
+    img[1, 1] = 65535
+    check_detect(capi, eng, img, 40, 8)
+
+
+@pytest.mark.parametrize("shape,dtype", [((100, 75), np.uint8), ((75, 100, 3), np.uint8), ((130, 97), np.uint16),
+                                          ((65, 33), np.uint8), ((64, 48, 3), np.uint8), ((1, 40), np.uint8),
+                                          ((40, 1), np.uint16), ((129, 16), np.uint8)])
+def test_ragged_shapes(capi, eng, shape, dtype):
+    rng = np.random.default_rng(sum(shape))
+    hi = 255 if dtype == np.uint8 else 4000
+    base = np.repeat(rng.random((max(1, shape[0] // 8 + 1),) + shape[1:2]) < 0.5, 8, axis=0)[:shape[0]]
+    img = np.where(base, int(hi * 0.8), int(hi * 0.1)).astype(np.float64)
+    if len(shape) == 3:
+        img = img[:, :, None] + rng.integers(-3, 4, size=shape)
+    else:
+        img = img + rng.integers(-3, 4, size=shape)
+    img = np.clip(img, 0, hi).astype(dtype)
+    check_detect(capi, eng, img, 12, 3)
+
+
+@pytest.mark.parametrize("dtype,c", [(np.uint8, 0), (np.uint16, 0), (np.uint8, 3)])
+def test_constant_image_gives_no_strips(capi, eng, dtype, c):
+    shape = (64, 80) + ((3,) if c else ())
+    img = np.full(shape, 77, dtype=dtype)
+    d = check_detect(capi, eng, img, 20, 4)
+    assert d["strips"] == [] and d["n_labels"] == 0
+
+
+def test_border_runs_and_run_lengths(capi, eng):
+    """runs of 4/5/6 at the top and 5/6/7 at the bottom, interior runs of 9/10/11 (opening keeps >= 10, border rule)."""
+    img = np.zeros((96, 160), np.uint8)
+    for k, ln in enumerate((4, 5, 6)):
+        img[0:ln, 10 + 12 * k:14 + 12 * k] = 200
+    for k, ln in enumerate((5, 6, 7)):
+        img[96 - ln:96, 60 + 12 * k:64 + 12 * k] = 200
+    for k, ln in enumerate((9, 10, 11)):
+        img[30:30 + ln, 100 + 12 * k:104 + 12 * k] = 200
+    img[40:90, 20:30] = 200          # something big enough to be a strip
+    d = check_detect(capi, eng, img, 30, 6)
+    assert d["n_labels"] >= 5
+
+
+def test_component_at_origin_raises_background_label(capi, eng):
+    """labeled[0,0] != 0 -> `background_color` is a label id (detection.py:67); means must exceed it."""
+    img = np.zeros((120, 200), np.uint8)
+    img[0:40, 0:30] = 210            # touches (0,0): label 1, background_color = 1.0
+    img[50:110, 80:110] = 220
+    img[50:110, 150:180] = 1         # dark, below threshold
+    d = check_detect(capi, eng, img, 30, 10)
+    assert d["background"] == 1.0
+
+
+def test_overlapping_and_out_of_image_boxes(capi, eng):
+    """expanded boxes overlap (first in label order wins) and extend past the image (numpy clips the crop)."""
+    img = np.zeros((200, 300), np.uint8)
+    img[150:190, 20:40] = 200        # maxr = 150+120 = 270 > H
+    img[20:60, 25:45] = 210          # expanded box reaches down to 140: no overlap with the first? 20+120=140 < 150
+    img[30:70, 60:80] = 205          # overlaps box 2 after column expansion (25+40=65 >= 60)
+    img[100:140, 280:299] = 215      # maxc = 280+40 > W
+    d = check_detect(capi, eng, img, 120, 40)
+    assert len(d["accepted"]) < d["n_labels"]
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 7, 11, 16])
+def test_line_length_variants(capi, eng, L):
+    rng = np.random.default_rng(L)
+    base = np.repeat(rng.random((30, 120)) < 0.45, 5, axis=0)
+    img = np.where(base, 190, 20).astype(np.uint8)
+    img[3, :] = 20
+    check_detect(capi, eng, img, 25, 5, L=L)
+
+
+def test_many_small_components(capi, eng):
+    rng = np.random.default_rng(42)
+    base = np.repeat(rng.random((40, 600)) < 0.35, 10, axis=0)
+    img = (np.where(base, 3000, 100) + rng.integers(0, 50, size=base.shape)).astype(np.uint16)
+    d = check_detect(capi, eng, img, 40, 15)
+    assert d["n_labels"] > 300
+
+
+def test_batch_of_distinct_images_matches_per_image(capi, eng):
+    from image_analysis_amd.synth import synth_rgb
+    imgs = np.stack([synth_rgb(256, 384, 6, 100 + i) for i in range(5)])
+    mm_r, mm_c = gui_params(imgs[0])
+    res = eng.detect(imgs, mm_r, mm_c, 10)
+    for i in range(5):
+        check_detect(capi, eng, imgs[i], mm_r, mm_c, batch_index=i, res=res)
+
+
+def test_dropin_detect_returns_views_equal_to_oracle_crops(golden_dir):
+    import image_analysis_amd.detection as det
+    from image_analysis_amd.synth import synth_rgb
+    img = synth_rgb(384, 512, 8, 9)
+    det.min_maxc = int(img.shape[1] / 40)
+    det.min_maxr = int(det.min_maxc * 20)
+    crops = det.detect_lateral_flow_tests(img)
+    want = O.detect_lateral_flow_tests(img, det.min_maxr, det.min_maxc)
+    assert len(crops) == len(want) > 0
+    for a, b in zip(crops, want):
+        assert a.base is not None and np.shares_memory(a, img)
+        assert a.shape == b.shape and np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        det.detect_lateral_flow_tests(np.zeros((4, 4, 4, 4), np.uint8))
+    with pytest.raises(ValueError):
+        det.detect_lateral_flow_tests(np.zeros((8, 8, 4), np.uint8))
