@@ -43,6 +43,9 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+    # torch ships its own libamdhip64.so.7; it must be the one HIP runtime of the process, so load it first and let
+    # liblfa_hip.so bind to it (two HIP/HSA runtimes in one process do not both see the device).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
     lib.lfa_version.restype = i32

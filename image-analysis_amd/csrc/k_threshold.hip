@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
             hi = ge ? hi : mid - 1;
         }
         // pixels within 2^-40 (relative) of an interior edge: their bin could depend on the last bits of pow()
-        const int a = lo >= 1 ? lo : 1;
+        const int a = lo < 1 ? 1 : (lo > 255 ? 255 : lo);
         const int b = lo + 1 <= 255 ? lo + 1 : 255;
         amb += near_rel(g, st[a]) || near_rel(g, st[b]);
         const int bin = lo > 255 ? 255 : lo;
