@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- LFA strips analysed per second (detect + profile + peaks) on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): a batch of 1024 synthetic 2048x1536 colour images, 8 strips each, per GPU,
+resident in HBM before the timed region.  A step = one pass of lfa_analyze_batch over that batch (in chunks of
+--chunk images).  The batch is a pool of --pool distinct seeded images (image_analysis_amd.synth.synth_rgb) tiled on the
+device.  Multi-GPU: every rank owns its own batch (weak scaling, no data-path collective); the strip counts are
+summed with one all_reduce after the timed region.
+
+One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel of the step (found in warm-up with every
+kernel timed, then timed alone with HIP events inside the timed region); its algorithmic bytes are the image bytes one
+launch reads.  `cpu_baseline` is the oracle (numpy/scipy port of the reference arithmetic) on a bounded
+sample of the same images on the host, one core.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
+    ap.add_argument("--chunk", type=int, default=64, help="images per lfa_analyze_batch call")
+    ap.add_argument("--pool", type=int, default=16, help="distinct synthetic images tiled to the batch")
+    ap.add_argument("--height", type=int, default=1536)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=48, help="images for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    capi = importlib.import_module("image_analysis_amd._capi")
+    synth = importlib.import_module("image_analysis_amd.synth")
+
+    H, W, C = args.height, args.width, 3
+    B, CH = args.batch, min(args.chunk, args.batch)
+    mm_c = int(W / 40)
+    mm_r = int(mm_c * 20)
+    max_strips = 16
+    stride = int(H * .6) + 1
+    img_bytes = H * W * C
+
+    # ---- inputs: pool of distinct images (rank-dependent seeds), tiled to the batch on the device ----
+    pool_np = np.stack([synth.synth_rgb(H, W, 8, 1234 + rank * args.pool + i) for i in range(args.pool)])
+    pool = torch.from_numpy(pool_np.reshape(args.pool, -1)).to(dev)
+    idx = torch.arange(B, device=dev) % args.pool
+    batch = pool[idx].contiguous()                       # (B, H*W*3) uint8, resident in HBM
+    del pool
+    assert batch.data_ptr() % 16 == 0
+
+    eng = capi.Engine(device=local_rank, max_h=H, max_w=W, max_c=3, max_batch=CH)
+    strips = capi.dev_bytes(B * max_strips * capi.STRIP_DT.itemsize, dev)
+    counts = torch.zeros(B, dtype=torch.int32, device=dev)
+    info = capi.dev_bytes(B * capi.INFO_DT.itemsize, dev)
+    rois = capi.dev_bytes(B * max_strips * capi.ROI_DT.itemsize, dev)
+    profiles = torch.empty(B * max_strips * stride, dtype=torch.float64, device=dev)
+    peaks = capi.dev_bytes(B * max_strips * capi.PEAKS_DT.itemsize, dev)
+    stream = capi.current_stream_ptr(dev)
+
+    def step():
+        for b0 in range(0, B, CH):
+            nb = min(CH, B - b0)
+            capi._check(capi.lib.lfa_analyze_batch(
+                eng._h, batch.data_ptr() + b0 * img_bytes, capi.LFA_U8, nb, H, W, C, mm_r, mm_c, 10,
+                strips.data_ptr() + b0 * max_strips * capi.STRIP_DT.itemsize, max_strips,
+                counts.data_ptr() + b0 * 4, info.data_ptr() + b0 * capi.INFO_DT.itemsize,
+                rois.data_ptr() + b0 * max_strips * capi.ROI_DT.itemsize,
+                profiles.data_ptr() + b0 * max_strips * stride * 8, stride,
+                peaks.data_ptr() + b0 * max_strips * capi.PEAKS_DT.itemsize, stream))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up; with every kernel timed, to find the dominant one ----
+    dominant, warm_times = None, {}
+    if not args.no_kernel_timing:
+        eng.timing("*")
+    for _ in range(max(1, args.warmup)):
+        step()
+    torch.cuda.synchronize()
+    if not args.no_kernel_timing:
+        warm_times = eng.timing_read()
+        dominant = max(warm_times, key=lambda k: warm_times[k][0])
+        eng.timing(dominant)
+
+    # ---- timed region ----
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ktimes = eng.timing_read() if dominant else {}
+    eng.timing(None)
+
+    # ---- results of one step ----
+    inf = capi.from_device(info, capi.INFO_DT, B)
+    assert (inf["status"] == 0).all(), "strip capacity overflow"
+    n_strips = counts.sum().to(torch.int64)
+    amb = int(inf["ambiguous"].sum())
+    pk = capi.from_device(peaks, capi.PEAKS_DT, B * max_strips).reshape(B, max_strips)
+    cn = counts.cpu().numpy()
+    n_peaks = int(sum(int(pk[i, :cn[i]]["n_peaks"].sum()) for i in range(0, B, max(1, B // 64))))
+    if world > 1:
+        dist.all_reduce(n_strips, op=dist.ReduceOp.SUM)
+    total_strips = int(n_strips.item())
+
+    out = None
+    if rank == 0:
+        value = total_strips * args.steps / dt
+        images_s = world * B * args.steps / dt
+        roof = None
+        if dominant and dominant in ktimes and ktimes[dominant][1] > 0:
+            ms, launches = ktimes[dominant]
+            avg_ms = ms / launches
+            alg_bytes = CH * img_bytes                                   # one launch reads its chunk of images once
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")       # HBM bytes per launch from rocprofv3 --pmc passes
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                key = f"{dominant}:{H}x{W}x{C}:chunk{CH}"
+                traffic = tj.get(key)
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": alg_bytes}
+        cpu = None
+        if args.cpu_sample > 0 and world == 1:
+            from oracle import lfa_oracle as O
+            nsamp = min(args.cpu_sample, args.pool * 4)
+            t1 = time.perf_counter()
+            ns = 0
+            for i in range(nsamp):
+                ns += len(O.analyze_image(pool_np[i % args.pool], mm_r, mm_c))
+            tc = time.perf_counter() - t1
+            cpu = {"value": round(ns / tc, 2), "unit": "strips/s", "cores": 1, "kind": "port",
+                   "sample": f"{nsamp} images of the same workload ({args.pool} distinct), oracle/lfa_oracle.analyze_image, "
+                             f"{tc:.1f} s; the reference additionally runs canny+Hough (dead compute), so this is a lower bound on its time",
+                   "images_per_s": round(nsamp / tc, 3)}
+        out = {
+            "metric": "LFA strips analysed/sec (detect+profile+peaks)", "value": round(value, 1), "unit": "strips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {B} synthetic {W}x{H} RGB uint8 images per GPU, 8 strips each, "
+                                   f"end-to-end detect+profile+peaks", "images_per_gpu": B, "chunk": CH, "pool": args.pool,
+                       "min_maxr": mm_r, "min_maxc": mm_c, "parallelism": f"images sharded over {world} GPU(s), no collective on the data path"},
+            "images_per_s": round(images_s, 1), "strips_per_step": total_strips,
+            "e2e_fraction_of_hbm_roofline": round(images_s / world * img_bytes / (HBM_PEAK_GBS * 1e9), 4),
+            "ambiguous_pixels": amb, "peaks_in_sample": n_peaks,
+            "roofline": roof, "cpu_baseline": cpu,
+            "kernel_ms_warmup": {k: round(v[0], 3) for k, v in sorted(warm_times.items(), key=lambda kv: -kv[1][0])},
+        }
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -61,7 +61,9 @@ def _load():
     lib.lfa_gaussian_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, dbl, vp, i32, vp, i32, vp]
     lib.lfa_debug_fetch.argtypes = [vp, i32, i32, vp, i64, vp]
     lib.lfa_sync.argtypes = [vp, vp]
-    for name in ("lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant", "lfa_detect_batch",
+    lib.lfa_timing_enable.argtypes = [vp, C.c_char_p]
+    lib.lfa_timing_read.argtypes = [vp, i32, vp, vp, vp, vp]
+    for name in ("lfa_timing_enable", "lfa_timing_read","lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant", "lfa_detect_batch",
                  "lfa_profile_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch", "lfa_debug_fetch",
                  "lfa_sync"):
         getattr(lib, name).restype = i32
@@ -72,7 +74,7 @@ lib = _load()
 
 EXPORTED = ("lfa_version", "lfa_last_error", "lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant",
             "lfa_detect_batch", "lfa_profile_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch",
-            "lfa_debug_fetch", "lfa_sync")
+            "lfa_debug_fetch", "lfa_sync", "lfa_timing_enable", "lfa_timing_read")
 
 
 def _check(rc):
@@ -387,6 +389,21 @@ class Engine:
         _check(lib.lfa_debug_fetch(self._h, image_index, DBG_TABLE, out.data_ptr(), max(k, 1) * 20,
                                    current_stream_ptr(self.device)))
         return out.cpu().numpy().reshape(-1, 5)[:k]
+
+    def timing(self, kernel_filter):
+        """"*": time every kernel, "<name>": that kernel only, None: off (include/lfa.h lfa_timing_enable)."""
+        _check(lib.lfa_timing_enable(self._h, kernel_filter.encode() if kernel_filter else None))
+
+    def timing_read(self, max_entries=64):
+        names = C.create_string_buffer(32 * max_entries)
+        ms = (C.c_double * max_entries)()
+        cnt = (C.c_int32 * max_entries)()
+        n = C.c_int32(0)
+        _check(lib.lfa_timing_read(self._h, max_entries, names, ms, cnt, C.byref(n)))
+        out = {}
+        for k in range(n.value):
+            out[names.raw[32 * k:32 * k + 32].split(b"\0")[0].decode()] = (ms[k], cnt[k])
+        return out
 
     def sync(self):
         _check(lib.lfa_sync(self._h, current_stream_ptr(self.device)))

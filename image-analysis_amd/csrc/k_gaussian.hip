@@ -76,11 +76,11 @@ hipError_t launch_gaussian_w(const Job& j, const double* w, int radius, void* ou
     const size_t lds = (size_t)kTH * IW * sizeof(double) + (size_t)(kTH + 2 * radius) * IW * px;
     const dim3 grid((E + kTE - 1) / kTE, (j.H + kTH - 1) / kTH, j.n);
     if (j.dtype == LFA_U8) {
-        if (out_f32) hipLaunchKernelGGL((k_gaussian<uint8_t, float>), grid, dim3(256), lds, s, j, gw, (float*)out);
-        else         hipLaunchKernelGGL((k_gaussian<uint8_t, double>), grid, dim3(256), lds, s, j, gw, (double*)out);
+        if (out_f32) LFA_LAUNCH("k_gaussian", (k_gaussian<uint8_t, float>), grid, dim3(256), lds, s, j, gw, (float*)out);
+        else         LFA_LAUNCH("k_gaussian", (k_gaussian<uint8_t, double>), grid, dim3(256), lds, s, j, gw, (double*)out);
     } else {
-        if (out_f32) hipLaunchKernelGGL((k_gaussian<uint16_t, float>), grid, dim3(256), lds, s, j, gw, (float*)out);
-        else         hipLaunchKernelGGL((k_gaussian<uint16_t, double>), grid, dim3(256), lds, s, j, gw, (double*)out);
+        if (out_f32) LFA_LAUNCH("k_gaussian", (k_gaussian<uint16_t, float>), grid, dim3(256), lds, s, j, gw, (float*)out);
+        else         LFA_LAUNCH("k_gaussian", (k_gaussian<uint16_t, double>), grid, dim3(256), lds, s, j, gw, (double*)out);
     }
     return hipGetLastError();
 }

@@ -228,17 +228,17 @@ hipError_t launch_label(const Job& j, hipStream_t s) {
     const dim3 gcol((j.W + 255) / 256, j.n);
     hipError_t e = hipMemsetAsync(j.firstbits, 0, (size_t)j.n * j.H * j.W64 * sizeof(uint64_t), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_runs_count, gcol, dim3(256), 0, s, j);
-    hipLaunchKernelGGL(k_col_scan, dim3(j.n), dim3(256), 0, s, j);
-    hipLaunchKernelGGL(k_runs_fill, gcol, dim3(256), 0, s, j);
+    LFA_LAUNCH("k_runs_count", k_runs_count, gcol, dim3(256), 0, s, j);
+    LFA_LAUNCH("k_col_scan", k_col_scan, dim3(j.n), dim3(256), 0, s, j);
+    LFA_LAUNCH("k_runs_fill", k_runs_fill, gcol, dim3(256), 0, s, j);
     int gx = (4096 + j.n - 1) / j.n;
     if (gx < 8) gx = 8;
     if (gx > 256) gx = 256;
     const dim3 grun(gx, j.n);
-    hipLaunchKernelGGL(k_union, grun, dim3(256), 0, s, j);
-    hipLaunchKernelGGL(k_flatten, grun, dim3(256), 0, s, j);
-    hipLaunchKernelGGL(k_rank_scan, dim3(j.n), dim3(1024), 0, s, j);
-    hipLaunchKernelGGL(k_label_roots, grun, dim3(256), 0, s, j);
+    LFA_LAUNCH("k_union", k_union, grun, dim3(256), 0, s, j);
+    LFA_LAUNCH("k_flatten", k_flatten, grun, dim3(256), 0, s, j);
+    LFA_LAUNCH("k_rank_scan", k_rank_scan, dim3(j.n), dim3(1024), 0, s, j);
+    LFA_LAUNCH("k_label_roots", k_label_roots, grun, dim3(256), 0, s, j);
     return hipGetLastError();
 }
 

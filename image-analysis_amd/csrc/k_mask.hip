@@ -120,10 +120,10 @@ static void launch_mode(const Job& j, hipStream_t s) {
     const bool vec = j.aligned16 && (j.W % 16 == 0);
     if (vec) {
         const int64_t items = (int64_t)j.HB * (j.W >> 4);
-        hipLaunchKernelGGL((k_mask<MODE, V, true>), dim3((unsigned)((items + 255) / 256), j.n), dim3(256), 0, s, j);
+        LFA_LAUNCH("k_mask", (k_mask<MODE, V, true>), dim3((unsigned)((items + 255) / 256), j.n), dim3(256), 0, s, j);
     } else {
         const int64_t items = (int64_t)j.HB * j.W;
-        hipLaunchKernelGGL((k_mask<MODE, V, false>), dim3((unsigned)((items + 255) / 256), j.n), dim3(256), 0, s, j);
+        LFA_LAUNCH("k_mask_scalar", (k_mask<MODE, V, false>), dim3((unsigned)((items + 255) / 256), j.n), dim3(256), 0, s, j);
     }
 }
 

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void k_peaks(const double* profiles, const int3
 hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const int32_t* counts, int slots, int inverse,
                            int rng, double* profiles, int stride, LfaPeaks* peaks, hipStream_t s) {
     if (n_rois <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_profile, dim3(n_rois), dim3(256), 0, s, j, rois, n_rois, counts, slots, inverse, rng, profiles,
+    LFA_LAUNCH("k_profile", k_profile, dim3(n_rois), dim3(256), 0, s, j, rois, n_rois, counts, slots, inverse, rng, profiles,
                        stride, peaks);
     return hipGetLastError();
 }
@@ -136,7 +136,7 @@ hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const i
 hipError_t launch_peaks(const double* profiles, const int32_t* lengths, int n, int stride, int inverse, int window,
                         int two, int rng, LfaPeaks* out, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_peaks, dim3(n), dim3(64), 0, s, profiles, lengths, n, stride, inverse, window, two, rng, out);
+    LFA_LAUNCH("k_peaks", k_peaks, dim3(n), dim3(64), 0, s, profiles, lengths, n, stride, inverse, window, two, rng, out);
     return hipGetLastError();
 }
 

@@ -171,12 +171,12 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
 }
 
 hipError_t launch_regions(const Job& j, const OutPtrs& o, hipStream_t s) {
-    hipLaunchKernelGGL(k_candidates, dim3(j.n), dim3(256), 0, s, j);
+    LFA_LAUNCH("k_candidates", k_candidates, dim3(j.n), dim3(256), 0, s, j);
     int gx = (4096 + j.n - 1) / j.n;
     if (gx < 4) gx = 4;
     if (gx > 128) gx = 128;
-    hipLaunchKernelGGL(k_box_means, dim3(gx, j.n), dim3(256), 0, s, j);
-    hipLaunchKernelGGL(k_finalize, dim3(j.n), dim3(64), 0, s, j, o);
+    LFA_LAUNCH("k_box_means", k_box_means, dim3(gx, j.n), dim3(256), 0, s, j);
+    LFA_LAUNCH("k_finalize", k_finalize, dim3(j.n), dim3(64), 0, s, j, o);
     return hipGetLastError();
 }
 

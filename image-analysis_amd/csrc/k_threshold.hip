@@ -406,37 +406,37 @@ static int blocks_per_image(const Job& j, int px_per_block) {
 
 #define LFA_DISPATCH_V(KERNEL, GRID, BLOCK, STREAM, JOB)                                         \
     switch ((JOB).gray_variant) {                                                                \
-        case 0: hipLaunchKernelGGL(KERNEL<0>, GRID, BLOCK, 0, STREAM, JOB); break;               \
-        case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, BLOCK, 0, STREAM, JOB); break;               \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, BLOCK, 0, STREAM, JOB); break;               \
-        case 3: hipLaunchKernelGGL(KERNEL<3>, GRID, BLOCK, 0, STREAM, JOB); break;               \
-        case 4: hipLaunchKernelGGL(KERNEL<4>, GRID, BLOCK, 0, STREAM, JOB); break;               \
-        default: hipLaunchKernelGGL(KERNEL<5>, GRID, BLOCK, 0, STREAM, JOB); break;              \
+        case 0: LFA_LAUNCH(#KERNEL, KERNEL<0>, GRID, BLOCK, 0, STREAM, JOB); break;              \
+        case 1: LFA_LAUNCH(#KERNEL, KERNEL<1>, GRID, BLOCK, 0, STREAM, JOB); break;              \
+        case 2: LFA_LAUNCH(#KERNEL, KERNEL<2>, GRID, BLOCK, 0, STREAM, JOB); break;              \
+        case 3: LFA_LAUNCH(#KERNEL, KERNEL<3>, GRID, BLOCK, 0, STREAM, JOB); break;              \
+        case 4: LFA_LAUNCH(#KERNEL, KERNEL<4>, GRID, BLOCK, 0, STREAM, JOB); break;              \
+        default: LFA_LAUNCH(#KERNEL, KERNEL<5>, GRID, BLOCK, 0, STREAM, JOB); break;             \
     }
 
 hipError_t launch_threshold(const Job& j, hipStream_t s) {
-    hipLaunchKernelGGL(k_init_info, dim3((j.n + 255) / 256), dim3(256), 0, s, j);
+    LFA_LAUNCH("k_init_info", k_init_info, dim3((j.n + 255) / 256), dim3(256), 0, s, j);
     if (j.C == 3) {
         hipError_t e = hipMemsetAsync(j.hist, 0, (size_t)j.n * j.hist_stride * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
         const dim3 grid(blocks_per_image(j, 256 * 64), j.n);
         LFA_DISPATCH_V(k_minmax_rgb, grid, dim3(256), s, j);
-        hipLaunchKernelGGL(k_edges_rgb, dim3(j.n), dim3(320), 0, s, j);
+        LFA_LAUNCH("k_edges_rgb", k_edges_rgb, dim3(j.n), dim3(320), 0, s, j);
         LFA_DISPATCH_V(k_hist_rgb, grid, dim3(256), s, j);
-        hipLaunchKernelGGL(k_otsu_rgb, dim3(j.n), dim3(64), 0, s, j);
+        LFA_LAUNCH("k_otsu_rgb", k_otsu_rgb, dim3(j.n), dim3(64), 0, s, j);
     } else if (j.dtype == LFA_U8) {
         hipError_t e = hipMemsetAsync(j.hist, 0, (size_t)j.n * j.hist_stride * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
         const dim3 grid(blocks_per_image(j, 256 * 128), j.n);
-        hipLaunchKernelGGL(k_hist_u8, grid, dim3(256), 0, s, j);
-        hipLaunchKernelGGL(k_otsu_int, dim3(j.n), dim3(256), 0, s, j);
+        LFA_LAUNCH("k_hist_u8", k_hist_u8, grid, dim3(256), 0, s, j);
+        LFA_LAUNCH("k_otsu_int", k_otsu_int, dim3(j.n), dim3(256), 0, s, j);
     } else {
         const dim3 grid(blocks_per_image(j, 256 * 64), j.n);
-        hipLaunchKernelGGL(k_minmax_u16, grid, dim3(256), 0, s, j);
-        hipLaunchKernelGGL(k_zero_hist_u16, dim3(16, j.n), dim3(256), 0, s, j);
+        LFA_LAUNCH("k_minmax_u16", k_minmax_u16, grid, dim3(256), 0, s, j);
+        LFA_LAUNCH("k_zero_hist_u16", k_zero_hist_u16, dim3(16, j.n), dim3(256), 0, s, j);
         const dim3 gridh(blocks_per_image(j, 1024 * 64), j.n);
-        hipLaunchKernelGGL(k_hist_u16, gridh, dim3(1024), 0, s, j);
-        hipLaunchKernelGGL(k_otsu_int, dim3(j.n), dim3(256), 0, s, j);
+        LFA_LAUNCH("k_hist_u16", k_hist_u16, gridh, dim3(1024), 0, s, j);
+        LFA_LAUNCH("k_otsu_int", k_otsu_int, dim3(j.n), dim3(256), 0, s, j);
     }
     return hipGetLastError();
 }

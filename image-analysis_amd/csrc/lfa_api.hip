@@ -36,7 +36,42 @@ struct Buf {
     size_t bytes = 0;
 };
 
+// per-kernel hipEvent brackets (lfa_timing_*); events are pooled and reused after every read
+struct EventTimer : lfa::KernelTimer {
+    struct Rec { std::string name; hipEvent_t a, b; };
+    std::string filter;                // "*" = every kernel, else exact kernel name
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    bool open = false;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    void begin(const char* name, hipStream_t s) override {
+        open = false;
+        if (filter != "*" && filter != name) return;
+        Rec r{name, get(), get()};
+        if (!r.a || !r.b) return;
+        if (hipEventRecord(r.a, s) != hipSuccess) return;
+        recs.push_back(r);
+        open = true;
+    }
+    void end(hipStream_t s) override {
+        if (!open) return;
+        (void)hipEventRecord(recs.back().b, s);
+        open = false;
+    }
+    ~EventTimer() override {
+        for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
 }  // namespace
+
+thread_local lfa::KernelTimer* lfa::g_timer = nullptr;
 
 struct LfaContext {
     int device = 0;
@@ -46,6 +81,7 @@ struct LfaContext {
         cand_ok, lut8, lut16, rois;
     lfa::Job last{};
     bool have_last = false;
+    EventTimer* timer = nullptr;
     std::vector<Buf*> all() {
         return {&info, &hist, &edges, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &firstbits, &wordrank,
                 &root_of_label, &cand, &cand_ok, &lut8, &lut16, &rois};
@@ -53,6 +89,11 @@ struct LfaContext {
 };
 
 namespace {
+
+struct TimerScope {
+    explicit TimerScope(LfaContext* h) { lfa::g_timer = h ? h->timer : nullptr; }
+    ~TimerScope() { lfa::g_timer = nullptr; }
+};
 
 int ensure(Buf& b, size_t bytes) {
     if (bytes <= b.bytes) return LFA_OK;
@@ -160,6 +201,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if ((rc = ensure_workspace(h, n, H, W, dtype, L, max_strips))) return rc;
     lfa::Job j = make_job(h, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
     lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
+    TimerScope ts(h);
     LFA_HIP(lfa::launch_threshold(j, s));
     LFA_HIP(lfa::launch_mask(j, s));
     LFA_HIP(lfa::launch_label(j, s));
@@ -213,8 +255,9 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
 
 int lfa_destroy(LfaHandle h) {
     if (!h) return LFA_OK;
-    hipSetDevice(h->device);
-    for (Buf* b : h->all()) if (b->p) hipFree(b->p);
+    (void)hipSetDevice(h->device);
+    for (Buf* b : h->all()) if (b->p) (void)hipFree(b->p);
+    delete h->timer;
     delete h;
     return LFA_OK;
 }
@@ -266,6 +309,7 @@ int lfa_profile_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
     j.images = (const uint8_t*)images;
     j.img_bytes = (int64_t)H * W * C * (dtype == LFA_U16 ? 2 : 1);
     j.n = n; j.H = H; j.W = W; j.C = C; j.dtype = dtype;
+    TimerScope ts(h);
     LFA_HIP(lfa::launch_profiles(j, rois, n_rois, nullptr, 0, inverse, range, out_profiles, profile_stride, out_peaks,
                                  (hipStream_t)stream));
     return LFA_OK;
@@ -279,6 +323,7 @@ int lfa_peaks_batch(LfaHandle h, const double* profiles, const int32_t* lengths,
     if (!profiles || !lengths || !out_peaks) return fail(LFA_ERR_ARG, "null pointer");
     if (profile_stride < 1 || window_size < 0) return fail(LFA_ERR_ARG, "bad stride / window");
     LFA_HIP(hipSetDevice(h->device));
+    TimerScope ts(h);
     LFA_HIP(lfa::launch_peaks(profiles, lengths, n_profiles, profile_stride, inverse, window_size, two_peaks, range,
                               out_peaks, (hipStream_t)stream));
     return LFA_OK;
@@ -302,6 +347,7 @@ int lfa_analyze_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
     rc = detect_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts,
                      out_info, out_rois, (hipStream_t)stream, &j);
     if (rc) return rc;
+    TimerScope ts(h);
     LFA_HIP(lfa::launch_profiles(j, out_rois, n * max_strips, out_counts, max_strips, 0, 15, out_profiles, profile_stride,
                                  out_peaks, (hipStream_t)stream));
     return LFA_OK;
@@ -332,6 +378,7 @@ int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H,
     j.images = (const uint8_t*)images;
     j.img_bytes = (int64_t)H * W * C * (dtype == LFA_U16 ? 2 : 1);
     j.n = n; j.H = H; j.W = W; j.C = C; j.dtype = dtype;
+    TimerScope ts(h);
     LFA_HIP(lfa::launch_gaussian_w(j, w, radius, out, out_f32, (hipStream_t)stream));
     return LFA_OK;
 }
@@ -343,6 +390,46 @@ int lfa_debug_fetch(LfaHandle h, int image_index, int what, void* out, int64_t o
     LFA_HIP(hipSetDevice(h->device));
     hipError_t e = lfa::launch_debug(h->last, image_index, what, out, out_bytes, (hipStream_t)stream);
     if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? LFA_ERR_ARG : LFA_ERR_HIP, "lfa_debug_fetch(what=%d): %s", what, hipGetErrorString(e));
+    return LFA_OK;
+}
+
+int lfa_timing_enable(LfaHandle h, const char* kernel_filter) {
+    if (!h) return fail(LFA_ERR_ARG, "null handle");
+    LFA_HIP(hipSetDevice(h->device));
+    if (!kernel_filter || !*kernel_filter) {
+        if (h->timer) { LFA_HIP(hipDeviceSynchronize()); delete h->timer; h->timer = nullptr; }
+        return LFA_OK;
+    }
+    if (!h->timer) h->timer = new (std::nothrow) EventTimer();
+    if (!h->timer) return fail(LFA_ERR_NOMEM, "out of host memory");
+    h->timer->filter = kernel_filter;
+    return LFA_OK;
+}
+
+int lfa_timing_read(LfaHandle h, int max_entries, char* names, double* total_ms, int32_t* launches, int32_t* n_out) {
+    if (!h || !names || !total_ms || !launches || !n_out) return fail(LFA_ERR_ARG, "null argument");
+    *n_out = 0;
+    if (!h->timer) return LFA_OK;
+    LFA_HIP(hipSetDevice(h->device));
+    LFA_HIP(hipDeviceSynchronize());
+    EventTimer* t = h->timer;
+    int n = 0;
+    for (auto& r : t->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) ms = 0.f;
+        int k = 0;
+        for (; k < n; ++k) if (std::strncmp(names + 32 * k, r.name.c_str(), 31) == 0) break;
+        if (k == n) {
+            if (n >= max_entries) { t->pool.push_back(r.a); t->pool.push_back(r.b); continue; }
+            std::memset(names + 32 * n, 0, 32);
+            std::strncpy(names + 32 * n, r.name.c_str(), 31);
+            total_ms[n] = 0.0; launches[n] = 0; ++n;
+        }
+        total_ms[k] += ms; launches[k] += 1;
+        t->pool.push_back(r.a); t->pool.push_back(r.b);
+    }
+    t->recs.clear();
+    *n_out = n;
     return LFA_OK;
 }
 

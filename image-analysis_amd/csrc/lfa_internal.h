@@ -57,6 +57,22 @@ struct OutPtrs {
     LfaRoi* rois;            // [n][max_strips] or null
 };
 
+// Optional per-kernel timing (diagnostics for bench.py): when the calling thread has a timer installed, every launch
+// made through LFA_LAUNCH is bracketed by two hipEventRecord calls on the launch stream.
+struct KernelTimer {
+    virtual void begin(const char* name, hipStream_t s) = 0;
+    virtual void end(hipStream_t s) = 0;
+    virtual ~KernelTimer() {}
+};
+extern thread_local KernelTimer* g_timer;
+
+#define LFA_LAUNCH(NAME, KERNEL, GRID, BLOCK, LDS, STREAM, ...)                         \
+    do {                                                                                \
+        if (lfa::g_timer) lfa::g_timer->begin(NAME, STREAM);                            \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);              \
+        if (lfa::g_timer) lfa::g_timer->end(STREAM);                                    \
+    } while (0)
+
 // --- launchers (each enqueues on `s` and returns the launch status) -----------------------------------------------
 hipError_t launch_threshold(const Job& j, hipStream_t s);                 // min/max, histogram, Otsu -> info
 hipError_t launch_mask(const Job& j, hipStream_t s);                      // thresholded image -> maskT

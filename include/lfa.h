@@ -187,6 +187,15 @@ int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H,
 /* Rasterise intermediate `what` of image `image_index` of the LAST detect/analyze call into `out` (device). */
 int lfa_debug_fetch(LfaHandle h, int image_index, int what, void* out, int64_t out_bytes, void* stream);
 
+/* ---- per-kernel timing for bench.py (no counterpart in the reference) ---------------------------------------------- */
+
+/* kernel_filter: "*" brackets every kernel launch made through this handle with a pair of hipEvents on the launch
+ * stream, "<kernel name>" only that kernel, NULL or "" switches timing off.  lfa_timing_read waits for the device,
+ * returns the summed milliseconds and launch counts per kernel name since the last read (names: max_entries slots of
+ * 32 bytes, HOST memory) and forgets them. */
+int lfa_timing_enable(LfaHandle h, const char* kernel_filter);
+int lfa_timing_read(LfaHandle h, int max_entries, char* names, double* total_ms, int32_t* launches, int32_t* n_out);
+
 /* Block until everything enqueued on `stream` through this handle has finished. */
 int lfa_sync(LfaHandle h, void* stream);
 
