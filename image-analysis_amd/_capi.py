@@ -54,6 +54,8 @@ def _load():
     lib.lfa_destroy.argtypes = [vp]
     lib.lfa_set_gamma_lut.argtypes = [vp, i32, vp, i32]
     lib.lfa_set_gray_variant.argtypes = [vp, i32]
+    lib.lfa_set_debug_flags.argtypes = [vp, i32]
+    lib.lfa_set_debug_flags.restype = i32
     lib.lfa_detect_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     lib.lfa_profile_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp]
     lib.lfa_peaks_batch.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
@@ -73,6 +75,7 @@ def _load():
 lib = _load()
 
 EXPORTED = ("lfa_version", "lfa_last_error", "lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant",
+            "lfa_set_debug_flags",
             "lfa_detect_batch", "lfa_profile_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch",
             "lfa_debug_fetch", "lfa_sync", "lfa_timing_enable", "lfa_timing_read")
 
@@ -389,6 +392,9 @@ class Engine:
         _check(lib.lfa_debug_fetch(self._h, image_index, DBG_TABLE, out.data_ptr(), max(k, 1) * 20,
                                    current_stream_ptr(self.device)))
         return out.cpu().numpy().reshape(-1, 5)[:k]
+
+    def set_debug_flags(self, flags):
+        _check(lib.lfa_set_debug_flags(self._h, int(flags)))
 
     def timing(self, kernel_filter):
         """"*": time every kernel, "<name>": that kernel only, None: off (include/lfa.h lfa_timing_enable)."""

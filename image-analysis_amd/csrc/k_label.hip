@@ -155,58 +155,97 @@ __global__ __launch_bounds__(256) void k_union(Job j) {
     }
 }
 
-// after k_union: point every run at its root, fold area / bbox into the root, flag the root's first pixel
+// after k_union: point every run at its root, fold area / bbox into the root, flag the root's first pixel.
+// Runs of one component sit next to each other in the run list (adjacent columns), so the lanes of a wave mostly share
+// a root: they are combined with wave reductions and ONE lane issues the atomics (otherwise every run of a strip
+// would queue five atomics on the same five words).
 __global__ __launch_bounds__(256) void k_flatten(Job j) {
     const int img = blockIdx.y;
     const uint32_t* off = j.col_cnt + (int64_t)img * (j.W + 1);
     const int64_t rbase = (int64_t)img * j.run_cap;
     const int nr = min((int)off[j.W], j.run_cap);
     int* parent = j.parent + rbase;
-    uint64_t* fb = j.firstbits + (int64_t)img * j.H * j.W64;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) {
-        int r = i;
-        for (;;) { const int p = __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (p == r) break; r = p; }
-        const uint32_t se = j.run_se[rbase + i];
-        const int s = (int)(se & 0xffffu), e = (int)(se >> 16), c = j.run_col[rbase + i];
-        if (r != i) {
-            __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            atomicAdd(&j.area[rbase + r], e - s + 1);
-            int* bb = j.bbox + (rbase + r) * 4;
-            atomicMin(&bb[0], s); atomicMin(&bb[1], c); atomicMax(&bb[2], e + 1); atomicMax(&bb[3], c + 1);
-        } else {
-            atomicOr((unsigned long long*)&fb[(int64_t)s * j.W64 + (c >> 6)], 1ull << (c & 63));
+    uint64_t* fb = j.firstbits + (int64_t)img * j.nwp;
+    const int lane = threadIdx.x & 63;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < nr; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        const bool active = i < nr;
+        int r = i, s = 0, e = -1, c = 0;
+        if (active) {
+            for (;;) { const int p = __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (p == r) break; r = p; }
+            const uint32_t se = j.run_se[rbase + i];
+            s = (int)(se & 0xffffu); e = (int)(se >> 16); c = j.run_col[rbase + i];
+            if (r != i) __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else atomicOr((unsigned long long*)&fb[(int64_t)s * j.W64 + (c >> 6)], 1ull << (c & 63));
+        }
+        const bool need = active && r != i;
+        unsigned long long todo = __ballot(need);
+        while (todo) {                                             // wave-uniform loop over the distinct roots
+            const int leader = __ffsll(todo) - 1;
+            const int lr = __shfl(r, leader);
+            const bool mine = need && r == lr;
+            const unsigned long long grp = __ballot(mine);
+            const int len = (int)wave_sum_u32(mine ? (uint32_t)(e - s + 1) : 0u);
+            const int mnr = wave_min_i32(mine ? s : 0x7fffffff), mnc = wave_min_i32(mine ? c : 0x7fffffff);
+            const int mxr = wave_max_i32(mine ? e + 1 : -1), mxc = wave_max_i32(mine ? c + 1 : -1);
+            if (lane == leader) {
+                atomicAdd(&j.area[rbase + lr], len);
+                int* bb = j.bbox + (rbase + lr) * 4;
+                atomicMin(&bb[0], mnr); atomicMin(&bb[1], mnc); atomicMax(&bb[2], mxr); atomicMax(&bb[3], mxc);
+            }
+            todo &= ~grp;
         }
     }
 }
 
-// exclusive prefix popcount over the first-pixel bitmap of one image -> rank of every component in raster order
+// exclusive prefix popcount over the first-pixel bitmap of one image -> rank of every component in raster order.
+// One 1024-thread block per image; a tile is 4096 words (4 consecutive words per thread, 32-byte loads); tiles without
+// any set bit (almost all) skip the block scan.
 __global__ __launch_bounds__(1024) void k_rank_scan(Job j) {
     const int img = blockIdx.x;
-    const int64_t nw = (int64_t)j.H * j.W64;
-    const uint64_t* fb = j.firstbits + (int64_t)img * nw;
-    uint32_t* wr = j.wordrank + (int64_t)img * nw;
-    __shared__ uint32_t part[1024];
-    const int t = threadIdx.x;
-    const int64_t seg = (nw + 1023) / 1024;
-    const int64_t b0 = min(nw, t * seg), b1 = min(nw, b0 + seg);
-    uint32_t sum = 0;
-    for (int64_t k = b0; k < b1; ++k) sum += __popcll(fb[k]);
-    part[t] = sum;
-    __syncthreads();
+    const int64_t nwp = j.nwp;
+    const uint64_t* fb = j.firstbits + (int64_t)img * nwp;
+    uint32_t* wr = j.wordrank + (int64_t)img * nwp;
+    __shared__ uint32_t wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t carry = 0;
+    for (int64_t base = 0; base < nwp; base += 4096) {
+        const int64_t k = base + 4 * t;
+        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        if (k < nwp) {
+            const uint4 a = *(const uint4*)(fb + k), b = *(const uint4*)(fb + k + 2);
+            p0 = __popc(a.x) + __popc(a.y); p1 = __popc(a.z) + __popc(a.w);
+            p2 = __popc(b.x) + __popc(b.y); p3 = __popc(b.z) + __popc(b.w);
+        }
+        const uint32_t sum = p0 + p1 + p2 + p3;
+        const int any = __syncthreads_or(sum != 0);
+        uint32_t excl = 0, tot = 0;
+        if (any) {
+            uint32_t inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+            if (lane == 63) wsum[wv] = inc;
+            __syncthreads();
+            uint32_t woff = 0;
+            for (int q = 0; q < 16; ++q) { const uint32_t v = wsum[q]; tot += v; woff += (q < wv) ? v : 0u; }
+            excl = woff + inc - sum;
+            __syncthreads();
+        }
+        if (k < nwp) {
+            uint4 o;
+            o.x = carry + excl; o.y = o.x + p0; o.z = o.y + p1; o.w = o.z + p2;
+            *(uint4*)(wr + k) = o;
+        }
+        carry += tot;
+    }
     if (t == 0) {
-        uint32_t acc = 0;
-        for (int k = 0; k < 1024; ++k) { const uint32_t v = part[k]; part[k] = acc; acc += v; }
-        j.info[img].n_labels = (int)acc;
+        j.info[img].n_labels = (int)carry;
         j.info[img].label00 = (int)(fb[0] & 1ull);          // pixel (0,0) foreground <=> it is the first pixel of label 1
     }
-    __syncthreads();
-    uint32_t acc = part[t];
-    for (int64_t k = b0; k < b1; ++k) { wr[k] = acc; acc += __popcll(fb[k]); }
 }
 
 __device__ inline int label_of_root(const Job& j, int img, int s, int c) {
-    const int64_t nw = (int64_t)j.H * j.W64;
-    const int64_t wi = (int64_t)img * nw + (int64_t)s * j.W64 + (c >> 6);
+    const int64_t wi = (int64_t)img * j.nwp + (int64_t)s * j.W64 + (c >> 6);
     const uint64_t w = j.firstbits[wi];
     return (int)(j.wordrank[wi] + __popcll(w & ((1ull << (c & 63)) - 1ull))) + 1;
 }
@@ -226,7 +265,7 @@ __global__ __launch_bounds__(256) void k_label_roots(Job j) {
 
 hipError_t launch_label(const Job& j, hipStream_t s) {
     const dim3 gcol((j.W + 255) / 256, j.n);
-    hipError_t e = hipMemsetAsync(j.firstbits, 0, (size_t)j.n * j.H * j.W64 * sizeof(uint64_t), s);
+    hipError_t e = hipMemsetAsync(j.firstbits, 0, (size_t)j.n * j.nwp * sizeof(uint64_t), s);
     if (e != hipSuccess) return e;
     LFA_LAUNCH("k_runs_count", k_runs_count, gcol, dim3(256), 0, s, j);
     LFA_LAUNCH("k_col_scan", k_col_scan, dim3(j.n), dim3(256), 0, s, j);

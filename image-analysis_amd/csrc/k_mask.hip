@@ -25,6 +25,14 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
     const double g_next = (gb >= 0 && gb < 0x7ff0000000000000LL) ? __longlong_as_double(gb + 1) : g_thr;
     uint64_t* out = j.maskT + (int64_t)img * j.HB * W;
     uint32_t amb = 0;
+    // colour: integer form of the compare (k_threshold.hip g_threshold) unless the threshold is critical
+    uint32_t G_thr = 0;
+    bool integer_path = false;
+    if (MODE == 2) {
+        const uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
+        G_thr = eg[kEdgesI_MaskThr];
+        integer_path = eg[kEdgesI_MaskCrit] == 0;
+    }
 
     if (VEC) {
         const int ncg = W >> 4;
@@ -57,11 +65,19 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
                 } else {
                     uint32_t w[12];
                     load48(q, w);
+                    if (integer_path) {
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const double g = gray_u8<V>(byte_of(w, 3 * k), byte_of(w, 3 * k + 1), byte_of(w, 3 * k + 2));
-                        bits |= (g > g_thr ? 1u : 0u) << k;
-                        amb += near_rel(g, g_next) ? 1u : 0u;
+                        for (int k = 0; k < 16; ++k) {
+                            const uint32_t G = 2125u * byte_of(w, 3 * k) + 7154u * byte_of(w, 3 * k + 1) + 721u * byte_of(w, 3 * k + 2);
+                            bits |= (G >= G_thr ? 1u : 0u) << k;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const double g = gray_u8<V>(byte_of(w, 3 * k), byte_of(w, 3 * k + 1), byte_of(w, 3 * k + 2));
+                            bits |= (g > g_thr ? 1u : 0u) << k;
+                            amb += near_rel(g, g_next) ? 1u : 0u;
+                        }
                     }
                 }
                 return bits;
@@ -99,7 +115,9 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
                 bool bit;
                 if (MODE == 0) bit = (int)base[px] > x_thr;
                 else if (MODE == 1) bit = (int)((const uint16_t*)base)[px] > x_thr;
-                else {
+                else if (integer_path) {
+                    bit = (2125u * base[3 * px] + 7154u * base[3 * px + 1] + 721u * base[3 * px + 2]) >= G_thr;
+                } else {
                     const double g = gray_u8<V>(base[3 * px], base[3 * px + 1], base[3 * px + 2]);
                     bit = g > g_thr;
                     amb += near_rel(g, g_next) ? 1u : 0u;

@@ -54,10 +54,13 @@ __device__ inline void store_peaks(LfaPeaks* dst, const TwoPeaks& t, int length)
     *dst = r;
 }
 
-// One 256-thread block per ROI.  16 lanes share a row; 16 rows per sweep.
+// One 256-thread block per ROI.  The ROI's rows are read as aligned dwords; every (row, dword) pair is an independent
+// work item (so many loads are in flight per thread), the integer row sums are accumulated with LDS atomics, then
+// profile[r] = sum / count in float64.  Rows beyond kProfLds (or unaligned batches) take the plain path.
 __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int n_rois, const int32_t* counts, int slots,
                                                  int inverse, int rng, double* profiles, int stride, LfaPeaks* peaks) {
     __shared__ double sp[kProfLds];
+    __shared__ unsigned int rs[kProfLds];
     const int ri = blockIdx.x;
     if (ri >= n_rois) return;
     if (counts && (ri % slots) >= counts[ri / slots]) return;        // analyze path: slot beyond this image's strips
@@ -74,20 +77,50 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
     }
     const uint8_t* base = j.images + (int64_t)roi.image * j.img_bytes;
     const int C = j.C;
+    const int esz = (j.dtype == LFA_U16) ? 2 : 1;
     const int ne = (roi.c1 - roi.c0) * C;                 // elements per row
     const double cnt = (double)ne;
-    const int sub = t & 15, grp = t >> 4;
     const bool use_lds = len <= kProfLds;
-    for (int r = grp; r < len; r += 16) {
-        const int64_t e0 = ((int64_t)(roi.r0 + r) * j.W + roi.c0) * C;
-        unsigned long long s = 0;
-        if (j.dtype == LFA_U8) { for (int k = sub; k < ne; k += 16) s += base[e0 + k]; }
-        else { const uint16_t* b16 = (const uint16_t*)base; for (int k = sub; k < ne; k += 16) s += b16[e0 + k]; }
-        s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-        if (sub == 0) {
-            const double m = (double)s / cnt;             // ne == 0 -> 0/0 = NaN, like np.nanmean of an empty slice
-            prof[r] = m;
-            if (use_lds) sp[r] = m;
+    const int64_t row_bytes = (int64_t)j.W * C * esz;
+    // u8 row sums fit 32 bits for any supported width; u16 rows up to 65535 elements too (65535*65535 < 2^32)
+    if (use_lds && j.aligned16 && (row_bytes & 3) == 0 && ne > 0 && (esz == 1 || ne <= 65536)) {
+        for (int r = t; r < len; r += 256) rs[r] = 0;
+        __syncthreads();
+        const int64_t b0 = ((int64_t)roi.r0 * j.W + roi.c0) * C * esz;       // first byte of row 0 of the ROI
+        const int64_t nbytes = (int64_t)ne * esz;
+        const int64_t a0 = b0 & ~(int64_t)3;                                   // row_bytes % 4 == 0: same phase on every row
+        const int ndw = (int)(((b0 + nbytes + 3) & ~(int64_t)3) - a0) >> 2;    // dwords covering one row
+        const int items = len * ndw;
+#pragma unroll 4
+        for (int it = t; it < items; it += 256) {
+            const int r = it / ndw, d = it - r * ndw;
+            const int64_t a = a0 + 4 * (int64_t)d;                             // byte offset inside row r's line
+            unsigned int x = *(const unsigned int*)(base + (int64_t)r * row_bytes + a);
+            unsigned int vm = 0xffffffffu;
+            if (a < b0) vm &= 0xffffffffu << (8 * (int)(b0 - a));
+            if (a + 4 > b0 + nbytes) vm &= 0xffffffffu >> (8 * (int)(a + 4 - (b0 + nbytes)));
+            x &= vm;
+            const unsigned int s = (esz == 1) ? __builtin_amdgcn_sad_u8(x, 0u, 0u) : ((x & 0xffffu) + (x >> 16));
+            if (s) atomicAdd(&rs[r], s);
+        }
+        __syncthreads();
+        for (int r = t; r < len; r += 256) {
+            const double m = (double)rs[r] / cnt;
+            prof[r] = m; sp[r] = m;
+        }
+    } else {
+        const int sub = t & 15, grp = t >> 4;
+        for (int r = grp; r < len; r += 16) {
+            const int64_t e0 = ((int64_t)(roi.r0 + r) * j.W + roi.c0) * C;
+            unsigned long long s = 0;
+            if (esz == 1) { for (int k = sub; k < ne; k += 16) s += base[e0 + k]; }
+            else { const uint16_t* b16 = (const uint16_t*)base; for (int k = sub; k < ne; k += 16) s += b16[e0 + k]; }
+            s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+            if (sub == 0) {
+                const double m = (double)s / cnt;         // ne == 0 -> 0/0 = NaN, like np.nanmean of an empty slice
+                prof[r] = m;
+                if (use_lds) sp[r] = m;
+            }
         }
     }
     __syncthreads();

@@ -30,7 +30,11 @@ __global__ __launch_bounds__(256) void k_candidates(Job j) {
         __syncthreads();
         int offs = base;
         for (int k = 0; k < wv; ++k) offs += wcnt[k];
-        if (flag) j.cand[rbase + offs + __popcll(bal & ((1ull << lane) - 1ull))] = l + 1;
+        if (flag) {
+            const int64_t slot = (int64_t)img * j.cand_cap + offs + __popcll(bal & ((1ull << lane) - 1ull));
+            j.cand[slot] = l + 1;
+            j.cand_sum[slot * 3 + 0] = 0; j.cand_sum[slot * 3 + 1] = 0; j.cand_sum[slot * 3 + 2] = 0;
+        }
         __syncthreads();
         if (t == 0) base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
         __syncthreads();
@@ -38,46 +42,82 @@ __global__ __launch_bounds__(256) void k_candidates(Job j) {
     if (t == 0) j.info[img].n_candidates = base;
 }
 
-// mean of the ORIGINAL image over the expanded, clipped box of every candidate; flag = mean > label id at (0,0)
-__global__ __launch_bounds__(256) void k_box_means(Job j) {
+// Integer sums of the ORIGINAL image over the expanded, clipped box of every candidate (per channel for colour).
+// A box is cut into slices of 64 rows; every (candidate, slice) is one work item of one block, so a tall strip is
+// summed by ~16 blocks at once instead of one block walking 1000 rows.  Rows are read as aligned dwords (a row of a
+// strip is ~170 bytes): the channel of a byte is its offset in the image modulo 3.
+__global__ __launch_bounds__(256) void k_box_sums(Job j) {
     const int img = blockIdx.y;
     const int64_t rbase = (int64_t)img * j.run_cap;
+    const int64_t cbase = (int64_t)img * j.cand_cap;
     const int nc = j.info[img].n_candidates;
-    const double bg = (double)j.info[img].label00;
     const uint8_t* base = j.images + (int64_t)img * j.img_bytes;
     __shared__ unsigned long long part[4][3];
     const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
-    for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
-        const int root = j.root_of_label[rbase + j.cand[rbase + ci] - 1];
+    const int esz = (j.dtype == LFA_U16) ? 2 : 1;
+    const int64_t pxb = (int64_t)esz * j.C;                       // bytes per pixel
+    const int HB = j.HB;
+    const bool dwords = j.aligned16 != 0;
+    for (int wi = blockIdx.x; wi < nc * HB; wi += gridDim.x) {
+        const int ci = wi / HB, sl = wi - ci * HB;
+        const int root = j.root_of_label[rbase + j.cand[cbase + ci] - 1];
         const int* bb = j.bbox + (rbase + root) * 4;
         const int minr = bb[0], minc = bb[1];
         int maxr = max(bb[2], minr + j.min_maxr), maxc = max(bb[3], minc + j.min_maxc);
         maxr = min(maxr, j.H); maxc = min(maxc, j.W);
-        unsigned long long s0 = 0, s1 = 0, s2 = 0;
-        for (int r = minr + wv; r < maxr; r += 4) {
-            const int64_t rowpx = (int64_t)r * j.W;
-            for (int c = minc + lane; c < maxc; c += 64) {
-                const int64_t px = rowpx + c;
-                if (j.C == 3) { s0 += base[3 * px]; s1 += base[3 * px + 1]; s2 += base[3 * px + 2]; }
-                else if (j.dtype == LFA_U8) s0 += base[px];
-                else s0 += ((const uint16_t*)base)[px];
+        const int r0 = minr + sl * 64;
+        if (r0 >= maxr) continue;                                 // uniform for the block
+        const int r1 = min(maxr, r0 + 64);
+        unsigned int s0 = 0, s1 = 0, s2 = 0;
+        if (dwords && (((int64_t)j.W * pxb) & 3) == 0) {
+            // every (row, dword) of the slice is an independent item: several loads in flight per thread
+            const int64_t row_bytes = (int64_t)j.W * pxb;
+            const int64_t b0 = ((int64_t)r0 * j.W + minc) * pxb;              // first byte of the slice's first row
+            const int64_t nbytes = (int64_t)(maxc - minc) * pxb;
+            const int64_t a0 = b0 & ~(int64_t)3;                               // row_bytes % 4 == 0: same phase on every row
+            const int ndw = (int)(((b0 + nbytes + 3) & ~(int64_t)3) - a0) >> 2;
+            const int items = (r1 - r0) * ndw;
+            const int ph0 = (int)(a0 % 3);                                     // row_bytes % 3 == 0 for colour: same on every row
+#pragma unroll 4
+            for (int it = t; it < items; it += 256) {
+                const int rr = it / ndw, d = it - rr * ndw;
+                const int64_t a = a0 + 4 * (int64_t)d;
+                unsigned int x = *(const unsigned int*)(base + (int64_t)rr * row_bytes + a);
+                unsigned int vm = 0xffffffffu;
+                if (a < b0) vm &= 0xffffffffu << (8 * (int)(b0 - a));
+                if (a + 4 > b0 + nbytes) vm &= 0xffffffffu >> (8 * (int)(a + 4 - (b0 + nbytes)));
+                x &= vm;
+                if (j.C == 3) {
+                    const int ph = (ph0 + d) % 3;                              // (a0 + 4d) % 3, since 4 = 1 (mod 3)
+                    const unsigned int m0 = ph == 0 ? 0xff0000ffu : (ph == 1 ? 0x00ff0000u : 0x0000ff00u);
+                    const unsigned int m1 = ph == 0 ? 0x0000ff00u : (ph == 1 ? 0xff0000ffu : 0x00ff0000u);
+                    const unsigned int m2 = ph == 0 ? 0x00ff0000u : (ph == 1 ? 0x0000ff00u : 0xff0000ffu);
+                    s0 = __builtin_amdgcn_sad_u8(x & m0, 0u, s0);
+                    s1 = __builtin_amdgcn_sad_u8(x & m1, 0u, s1);
+                    s2 = __builtin_amdgcn_sad_u8(x & m2, 0u, s2);
+                } else if (esz == 1) {
+                    s0 = __builtin_amdgcn_sad_u8(x, 0u, s0);
+                } else {
+                    s0 += (x & 0xffffu) + (x >> 16);
+                }
+            }
+        } else {
+            for (int r = r0 + wv; r < r1; r += 4) {
+                const int64_t rowpx = (int64_t)r * j.W;
+                for (int c = minc + lane; c < maxc; c += 64) {
+                    const int64_t px = rowpx + c;
+                    if (j.C == 3) { s0 += base[3 * px]; s1 += base[3 * px + 1]; s2 += base[3 * px + 2]; }
+                    else if (esz == 1) s0 += base[px];
+                    else s0 += ((const uint16_t*)base)[px];
+                }
             }
         }
-        s0 = wave_sum_u64(s0); s1 = wave_sum_u64(s1); s2 = wave_sum_u64(s2);
-        if (lane == 0) { part[wv][0] = s0; part[wv][1] = s1; part[wv][2] = s2; }
+        const unsigned long long w0 = wave_sum_u64(s0), w1 = wave_sum_u64(s1), w2 = wave_sum_u64(s2);
+        if (lane == 0) { part[wv][0] = w0; part[wv][1] = w1; part[wv][2] = w2; }
         __syncthreads();
-        if (t == 0) {
-            unsigned long long a0 = 0, a1 = 0, a2 = 0;
-            for (int k = 0; k < 4; ++k) { a0 += part[k][0]; a1 += part[k][1]; a2 += part[k][2]; }
-            const double cnt = (double)((long long)(maxr - minr) * (long long)(maxc - minc));
-            double m;
-            if (j.C == 3) {
-                const double m0 = (double)a0 / cnt, m1 = (double)a1 / cnt, m2 = (double)a2 / cnt;
-                m = ((m0 + m1) + m2) / 3.0;
-            } else {
-                m = (double)a0 / cnt;
-            }
-            j.cand_ok[rbase + ci] = (m > bg) ? 1 : 0;
+        if (t < 3) {
+            const unsigned long long v = part[0][t] + part[1][t] + part[2][t] + part[3][t];
+            if (v) atomicAdd(&j.cand_sum[(cbase + ci) * 3 + t], v);
         }
         __syncthreads();
     }
@@ -97,13 +137,26 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
     __shared__ Acc kept[kMaxStripsLds];
     int na = 0;
     int status = 0;
-    for (int ci = 0; ci < nc; ++ci) {
-        if (!j.cand_ok[rbase + ci]) continue;                 // uniform: every lane reads the same byte
-        const int lab = j.cand[rbase + ci];
+    const int64_t cbase = (int64_t)img * j.cand_cap;
+    const double bg = (double)inf->label00;                   // detection.py:67: the label id at (0,0)
+    for (int ci = 0; ci < nc; ++ci) {                         // uniform: every lane walks the same candidates
+        const int lab = j.cand[cbase + ci];
         const int root = j.root_of_label[rbase + lab - 1];
         const int* bb = j.bbox + (rbase + root) * 4;
         const int minr = bb[0], minc = bb[1];
         const int maxr = max(bb[2], minr + j.min_maxr), maxc = max(bb[3], minc + j.min_maxc);
+        {   // np.mean of the clipped box (detection.py:76-81): exact integer sums, then the reference's divisions
+            const double cnt = (double)((long long)(min(maxr, j.H) - minr) * (long long)(min(maxc, j.W) - minc));
+            const unsigned long long* cs = j.cand_sum + (cbase + ci) * 3;
+            double m;
+            if (j.C == 3) {
+                const double m0 = (double)cs[0] / cnt, m1 = (double)cs[1] / cnt, m2 = (double)cs[2] / cnt;
+                m = ((m0 + m1) + m2) / 3.0;
+            } else {
+                m = (double)cs[0] / cnt;
+            }
+            if (!(m > bg)) continue;
+        }
         bool hit = false;
         for (int k = lane; k < na; k += 64) {
             const Acc a = acc[k];
@@ -172,10 +225,10 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
 
 hipError_t launch_regions(const Job& j, const OutPtrs& o, hipStream_t s) {
     LFA_LAUNCH("k_candidates", k_candidates, dim3(j.n), dim3(256), 0, s, j);
-    int gx = (4096 + j.n - 1) / j.n;
-    if (gx < 4) gx = 4;
-    if (gx > 128) gx = 128;
-    LFA_LAUNCH("k_box_means", k_box_means, dim3(gx, j.n), dim3(256), 0, s, j);
+    int gx = (16384 + j.n - 1) / j.n;
+    if (gx < 16) gx = 16;
+    if (gx > 1024) gx = 1024;
+    LFA_LAUNCH("k_box_sums", k_box_sums, dim3(gx, j.n), dim3(256), 0, s, j);
     LFA_LAUNCH("k_finalize", k_finalize, dim3(j.n), dim3(64), 0, s, j, o);
     return hipGetLastError();
 }

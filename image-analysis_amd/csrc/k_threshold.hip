@@ -114,16 +114,55 @@ __device__ inline double gamma_pow(double g) { return pow(g, 0.4); }
 
 // smallest double g in [gmin, gmax] with pred(g) true, where pred is monotone (false ... false true ... true);
 // +inf if pred(gmax) is false.  Bisection on the bit patterns (non-negative doubles are ordered like int64).
+// `guess` only speeds the search up (gallop outwards from it in steps of 16^k bit patterns, then bisect); any value works.
 template <class Pred>
-__device__ inline double first_true(double gmin, double gmax, const Pred& pred) {
+__device__ inline double first_true(double gmin, double gmax, double guess, const Pred& pred) {
     if (!pred(gmax)) return __longlong_as_double(0x7ff0000000000000LL);
     if (pred(gmin)) return gmin;
-    long long lo = __double_as_longlong(gmin), hi = __double_as_longlong(gmax);
+    long long lo = __double_as_longlong(gmin), hi = __double_as_longlong(gmax);   // pred(lo) false, pred(hi) true
+    if (hi - lo > 1 && guess == guess) {
+        long long g0 = __double_as_longlong(guess < 0.0 ? 0.0 : guess);
+        g0 = g0 <= lo ? lo + 1 : (g0 >= hi ? hi - 1 : g0);
+        long long step = 16;
+        if (pred(__longlong_as_double(g0))) {
+            hi = g0;
+            while (hi - step > lo) {
+                const long long c = hi - step;
+                if (pred(__longlong_as_double(c))) { hi = c; if (step < (1LL << 56)) step <<= 4; } else { lo = c; break; }
+            }
+        } else {
+            lo = g0;
+            while (lo + step < hi) {
+                const long long c = lo + step;
+                if (!pred(__longlong_as_double(c))) { lo = c; if (step < (1LL << 56)) step <<= 4; } else { hi = c; break; }
+            }
+        }
+    }
     while (hi - lo > 1) {
         const long long mid = lo + ((hi - lo) >> 1);
         if (pred(__longlong_as_double(mid))) hi = mid; else lo = mid;
     }
     return __longlong_as_double(hi);
+}
+
+// ---- integer form of a gray-space threshold ------------------------------------------------------------------------------
+// gray(b0,b1,b2) is within a few ulps of G / 2 550 000 with the INTEGER G = 2125*b0 + 7154*b1 + 721*b2 (0.2125, 0.7154,
+// 0.0721 scaled by 10^4, times 255).  Different G differ by >= 4e-7 relative, the float64 rounding of any of the
+// summation orders by < 4e-15, so `gray >= t` equals `G >= ceil(t * 2 550 000)` unless an integer lies within a
+// 2^-39 relative band around t * 2 550 000 -- then the threshold is "critical" and the image takes the float64 path.
+// The band also covers the 2^-40 ambiguity census, so an image on the integer path has no ambiguous pixel by construction.
+constexpr double kGScale = 2550000.0;
+constexpr uint32_t kGInf = 0xffffffffu;
+
+__device__ inline uint32_t gray_G(uint32_t p0, uint32_t p1, uint32_t p2) { return 2125u * p0 + 7154u * p1 + 721u * p2; }
+
+__device__ inline uint32_t g_threshold(double t, bool* critical) {
+    if (!(t < 1.0e300)) return kGInf;                      // unreachable edge
+    const double A = t * kGScale;
+    const double r = rint(A);
+    if (fabs(r - A) <= A * 1.8189894035458565e-12) *critical = true;     // 2^-39
+    const double c = ceil(A);
+    return c >= 4294967295.0 ? kGInf : (uint32_t)c;
 }
 
 __global__ __launch_bounds__(320) void k_edges_rgb(Job j) {
@@ -132,13 +171,24 @@ __global__ __launch_bounds__(320) void k_edges_rgb(Job j) {
     const double gmin = inf->gmin, gmax = inf->gmax;
     const double vmin = gamma_pow(gmin), vmax = gamma_pow(gmax);
     const int i = threadIdx.x;
+    uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
     if (i == 0) { inf->vmin = vmin; inf->vmax = vmax; inf->all_equal = (vmin == vmax) ? 1 : 0; }
-    if (i >= kEdges) return;
-    double* t = j.edges_g + (int64_t)img * kEdges;
-    if (vmin == vmax) { t[i] = (i == 0) ? gmin : __longlong_as_double(0x7ff0000000000000LL); return; }
-    const Linspace lin(vmin, vmax, kEdges);
-    const double e = lin(i);
-    t[i] = first_true(gmin, gmax, [e](double g) { return gamma_pow(g) >= e; });
+    bool crit = false;
+    if (i < kEdges) {
+        double* t = j.edges_g + (int64_t)img * kEdges;
+        double ti;
+        if (vmin == vmax) {
+            ti = (i == 0) ? gmin : __longlong_as_double(0x7ff0000000000000LL);
+        } else {
+            const Linspace lin(vmin, vmax, kEdges);
+            const double e = lin(i);
+            ti = first_true(gmin, gmax, pow(e, 2.5), [e](double g) { return gamma_pow(g) >= e; });
+        }
+        t[i] = ti;
+        eg[i] = (i == 0) ? 0u : g_threshold(ti, &crit);       // edge 0 (= gmin) is below every pixel
+    }
+    const int any = __syncthreads_or(((i >= 1 && i <= 255 && crit) || (j.debug_flags & 1)) ? 1 : 0);
+    if (i == 0) eg[kEdgesI_Crit] = (uint32_t)any;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -244,36 +294,64 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     const int cp = threadIdx.x & (kCopies - 1);
     uint32_t amb = 0;
-    auto add = [&](double g) {
-        // largest i in [0,256] with t[i] <= g   (t[0] = gmin <= g always)
-        int lo = 0, hi = 256;
-#pragma unroll
-        for (int it = 0; it < 9; ++it) {
-            const int mid = (lo + hi + 1) >> 1;
-            const bool ge = st[mid] <= g;
-            lo = ge ? mid : lo;
-            hi = ge ? hi : mid - 1;
-        }
+    // bin estimate in float32 (v = g^0.4 by exp2/log2, then the uniform-bin formula); the exact bin is then fixed up by
+    // compares against the edges, so the estimate only decides how many compares run
+    const float vminf = (float)j.info[img].vmin;
+    const float scalef = 256.0f / ((float)j.info[img].vmax - vminf);
+    const uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
+    const bool integer_path = eg[kEdgesI_Crit] == 0;
+    __shared__ uint32_t sg[kEdges + 1];
+    if (integer_path) {
+        for (int k = threadIdx.x; k < kEdges; k += 256) sg[k] = eg[k];
+        __syncthreads();
+    }
+    auto addG = [&](uint32_t G) {                          // integer path: see g_threshold
+        const float vf = __builtin_amdgcn_exp2f(0.4f * __builtin_amdgcn_logf((float)G * (1.0f / 2550000.0f)));
+        int k = (int)((vf - vminf) * scalef);
+        k = k < 0 ? 0 : (k > 255 ? 255 : k);
+        while (k > 0 && G < sg[k]) --k;                     // largest k in [0,255] with Gt[k] <= G  (Gt[0] = 0)
+        while (k < 255 && G >= sg[k + 1]) ++k;
+        atomicAdd(&sh[k * kCopies + cp], 1u);
+    };
+    auto add = [&](double g) {                             // float64 path (an edge is critical): exact compares + census
+        const float vf = __builtin_amdgcn_exp2f(0.4f * __builtin_amdgcn_logf((float)g));
+        int k = (int)((vf - vminf) * scalef);
+        k = k < 0 ? 0 : (k > 255 ? 255 : k);
+        while (k > 0 && g < st[k]) --k;                 // largest k in [0,255] with t[k] <= g  (t[0] = gmin <= g always)
+        while (k < 255 && g >= st[k + 1]) ++k;
         // pixels within 2^-40 (relative) of an interior edge: their bin could depend on the last bits of pow()
-        const int a = lo < 1 ? 1 : (lo > 255 ? 255 : lo);
-        const int b = lo + 1 <= 255 ? lo + 1 : 255;
+        const int a = k < 1 ? 1 : k;
+        const int b = k + 1 <= 255 ? k + 1 : 255;
         amb += near_rel(g, st[a]) || near_rel(g, st[b]);
-        const int bin = lo > 255 ? 255 : lo;
-        atomicAdd(&sh[bin * kCopies + cp], 1u);
+        atomicAdd(&sh[k * kCopies + cp], 1u);
     };
     int64_t done = 0;
-    if (j.aligned16) {
-        const int64_t ng = npix >> 4;
-        for (int64_t g = tid; g < ng; g += nth) {
-            uint32_t w[12];
-            load48(base + g * 48, w);
-#pragma unroll 4
-            for (int k = 0; k < 16; ++k)
-                add(gray_u8<V>(byte_of(w, 3 * k), byte_of(w, 3 * k + 1), byte_of(w, 3 * k + 2)));
+    if (integer_path) {
+        if (j.aligned16) {
+            const int64_t ng = npix >> 4;
+            for (int64_t g = tid; g < ng; g += nth) {
+                uint32_t w[12];
+                load48(base + g * 48, w);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) addG(gray_G(byte_of(w, 3 * k), byte_of(w, 3 * k + 1), byte_of(w, 3 * k + 2)));
+            }
+            done = ng << 4;
         }
-        done = ng << 4;
+        for (int64_t p = done + tid; p < npix; p += nth) addG(gray_G(base[3 * p], base[3 * p + 1], base[3 * p + 2]));
+    } else {
+        if (j.aligned16) {
+            const int64_t ng = npix >> 4;
+            for (int64_t g = tid; g < ng; g += nth) {
+                uint32_t w[12];
+                load48(base + g * 48, w);
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    add(gray_u8<V>(byte_of(w, 3 * k), byte_of(w, 3 * k + 1), byte_of(w, 3 * k + 2)));
+            }
+            done = ng << 4;
+        }
+        for (int64_t p = done + tid; p < npix; p += nth) add(gray_u8<V>(base[3 * p], base[3 * p + 1], base[3 * p + 2]));
     }
-    for (int64_t p = done + tid; p < npix; p += nth) add(gray_u8<V>(base[3 * p], base[3 * p + 1], base[3 * p + 2]));
     __syncthreads();
     uint32_t tot = 0;
 #pragma unroll
@@ -372,25 +450,62 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
 // ------------------------------------------------------------------------------------------------------------------
 // Otsu, colour path: 256 float bins, sequential like the reference (one lane), then the gray-space threshold.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_otsu_rgb(Job j) {
-    __shared__ OtsuScratch ws;
-    __shared__ uint32_t cnt[256];
+__global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
+    // Same arithmetic as lfa_algo.h otsu_float256 (checked on the host against skimage's formula): the four cumulative
+    // sums stay sequential (their rounding depends on the order) but run on four different waves at once; centres,
+    // products, divisions and variances are independent per bin and run one per thread.
+    __shared__ float c32[256], w1[256], w2[256];
+    __shared__ double ctr[256], prod[256], s1[256], s2[256], var[256];
     const int img = blockIdx.x;
     LfaImageInfo* inf = &j.info[img];
+    const int t = threadIdx.x;
     if (inf->all_equal) {
-        if (threadIdx.x == 0) { inf->v_thr_f = inf->vmin; inf->g_thr = __longlong_as_double(0x7ff0000000000000LL); }
+        if (t == 0) {
+            inf->v_thr_f = inf->vmin; inf->g_thr = __longlong_as_double(0x7ff0000000000000LL);
+            uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
+            eg[kEdgesI_MaskThr] = kGInf; eg[kEdgesI_MaskCrit] = 0u;
+        }
         return;
     }
-    for (int k = threadIdx.x; k < 256; k += 64) cnt[k] = j.hist[(int64_t)img * j.hist_stride + k];
+    const Linspace edges(inf->vmin, inf->vmax, kEdges);
+    {
+        const float c = (float)j.hist[(int64_t)img * j.hist_stride + t];
+        const double ce = (edges(t) + edges(t + 1)) / 2.0;
+        c32[t] = c; ctr[t] = ce; prod[t] = (double)c * ce;
+    }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    double centre;
-    const int idx = otsu_float256(cnt, inf->vmin, inf->vmax, &centre, &ws);
-    inf->otsu_bin = idx; inf->v_thr_f = centre;
+    if (t == 0)        { float a = 0.0f; for (int i = 0; i < 256; ++i) { a = a + c32[i]; w1[i] = a; } }
+    else if (t == 64)  { float a = 0.0f; for (int i = 255; i >= 0; --i) { a = a + c32[i]; w2[i] = a; } }
+    else if (t == 128) { double a = 0.0; for (int i = 0; i < 256; ++i) { a = a + prod[i]; s1[i] = a; } }
+    else if (t == 192) { double a = 0.0; for (int i = 255; i >= 0; --i) { a = a + prod[i]; s2[i] = a; } }
+    __syncthreads();
+    if (t < 255) {
+        const double m1 = s1[t] / (double)w1[t];
+        const double m2 = s2[t + 1] / (double)w2[t + 1];
+        const float ww = w1[t] * w2[t + 1];
+        const double d = m1 - m2;
+        var[t] = (double)ww * (d * d);
+    }
+    __syncthreads();
+    if (t != 0) return;
+    int best = 0;
+    double bv = var[0];
+    if (!lfa_isnan(bv))
+        for (int i = 1; i < 255; ++i) {
+            const double v = var[i];
+            if (!(v <= bv)) { bv = v; best = i; if (lfa_isnan(v)) break; }
+        }
+    const double centre = ctr[best];
+    inf->otsu_bin = best; inf->v_thr_f = centre;
     // mask = pow(gray, 0.4) > centre  <=>  gray >= T  with T the first double whose power exceeds the centre
-    const double T = first_true(inf->gmin, inf->gmax, [centre](double g) { return gamma_pow(g) > centre; });
+    const double T = first_true(inf->gmin, inf->gmax, pow(centre, 2.5), [centre](double g) { return gamma_pow(g) > centre; });
     const long long tb = __double_as_longlong(T);
     inf->g_thr = (tb > 0 && tb < 0x7ff0000000000000LL) ? __longlong_as_double(tb - 1) : T;
+    // integer form of `gray >= T` for k_mask (critical -> k_mask takes the float64 path)
+    uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
+    bool crit = false;
+    eg[kEdgesI_MaskThr] = g_threshold(T, &crit);
+    eg[kEdgesI_MaskCrit] = (crit || (j.debug_flags & 1)) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -423,7 +538,7 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
         LFA_DISPATCH_V(k_minmax_rgb, grid, dim3(256), s, j);
         LFA_LAUNCH("k_edges_rgb", k_edges_rgb, dim3(j.n), dim3(320), 0, s, j);
         LFA_DISPATCH_V(k_hist_rgb, grid, dim3(256), s, j);
-        LFA_LAUNCH("k_otsu_rgb", k_otsu_rgb, dim3(j.n), dim3(64), 0, s, j);
+        LFA_LAUNCH("k_otsu_rgb", k_otsu_rgb, dim3(j.n), dim3(256), 0, s, j);
     } else if (j.dtype == LFA_U8) {
         hipError_t e = hipMemsetAsync(j.hist, 0, (size_t)j.n * j.hist_stride * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;

@@ -26,30 +26,52 @@ namespace lfa {
 // remainder one by one; larger: split at n/2 rounded down to a multiple of 8.
 // ---------------------------------------------------------------------------------------------------------------
 template <class F>
-LFA_HD double np_pairwise(const F& f, int off, int n) {
+LFA_HD double np_pairwise_leaf(const F& f, int off, int n) {       // n <= 128
     if (n < 8) {
         double res = 0.0;
         for (int i = 0; i < n; ++i) res = res + f(off + i);
         return res;
     }
-    if (n <= 128) {
-        double r0 = f(off + 0), r1 = f(off + 1), r2 = f(off + 2), r3 = f(off + 3);
-        double r4 = f(off + 4), r5 = f(off + 5), r6 = f(off + 6), r7 = f(off + 7);
-        int i = 8;
-        const int lim = n - (n % 8);
-        for (; i < lim; i += 8) {
-            r0 = r0 + f(off + i + 0); r1 = r1 + f(off + i + 1); r2 = r2 + f(off + i + 2); r3 = r3 + f(off + i + 3);
-            r4 = r4 + f(off + i + 4); r5 = r5 + f(off + i + 5); r6 = r6 + f(off + i + 6); r7 = r7 + f(off + i + 7);
-        }
-        double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-        for (; i < n; ++i) res = res + f(off + i);
-        return res;
+    double r0 = f(off + 0), r1 = f(off + 1), r2 = f(off + 2), r3 = f(off + 3);
+    double r4 = f(off + 4), r5 = f(off + 5), r6 = f(off + 6), r7 = f(off + 7);
+    int i = 8;
+    const int lim = n - (n % 8);
+    for (; i < lim; i += 8) {
+        r0 = r0 + f(off + i + 0); r1 = r1 + f(off + i + 1); r2 = r2 + f(off + i + 2); r3 = r3 + f(off + i + 3);
+        r4 = r4 + f(off + i + 4); r5 = r5 + f(off + i + 5); r6 = r6 + f(off + i + 6); r7 = r7 + f(off + i + 7);
     }
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    const double a = np_pairwise(f, off, n2);
-    const double b = np_pairwise(f, off + n2, n - n2);
-    return a + b;
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res = res + f(off + i);
+    return res;
+}
+
+// The recursion of numpy's pairwise sum (split at n/2 rounded down to a multiple of 8 until a piece has <= 128
+// elements) written with an explicit stack, so that the device code has no recursive call (no scratch stack frames).
+template <class F>
+LFA_HD double np_pairwise(const F& f, int off, int n) {
+    if (n <= 128) return np_pairwise_leaf(f, off, n);
+    int f_off[28], f_n[28], f_stage[28];
+    double f_left[28];
+    int sp = 0;
+    f_off[0] = off; f_n[0] = n; f_stage[0] = 0; f_left[0] = 0.0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        const int cn = f_n[sp], co = f_off[sp];
+        if (cn <= 128) { ret = np_pairwise_leaf(f, co, cn); --sp; continue; }
+        int n2 = cn / 2;
+        n2 -= n2 % 8;
+        if (f_stage[sp] == 0) {
+            f_stage[sp] = 1;
+            ++sp; f_off[sp] = co; f_n[sp] = n2; f_stage[sp] = 0;
+        } else if (f_stage[sp] == 1) {
+            f_left[sp] = ret; f_stage[sp] = 2;
+            ++sp; f_off[sp] = co + n2; f_n[sp] = cn - n2; f_stage[sp] = 0;
+        } else {
+            ret = f_left[sp] + ret;
+            --sp;
+        }
+    }
+    return ret;
 }
 
 struct ArrAt {

@@ -77,14 +77,15 @@ struct LfaContext {
     int device = 0;
     int max_h = 0, max_w = 0, max_c = 0, max_batch = 0;
     int gray_variant = LFA_GRAY_FMA_102;
-    Buf info, hist, edges, maskT, col_cnt, run_se, run_col, parent, area, bbox, firstbits, wordrank, root_of_label, cand,
-        cand_ok, lut8, lut16, rois;
+    int debug_flags = 0;
+    Buf info, hist, edges, edges_i, maskT, col_cnt, run_se, run_col, parent, area, bbox, firstbits, wordrank, root_of_label, cand,
+        cand_sum, lut8, lut16, rois;
     lfa::Job last{};
     bool have_last = false;
     EventTimer* timer = nullptr;
     std::vector<Buf*> all() {
-        return {&info, &hist, &edges, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &firstbits, &wordrank,
-                &root_of_label, &cand, &cand_ok, &lut8, &lut16, &rois};
+        return {&info, &hist, &edges, &edges_i, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &firstbits, &wordrank,
+                &root_of_label, &cand, &cand_sum, &lut8, &lut16, &rois};
     }
 };
 
@@ -123,6 +124,7 @@ int ensure_workspace(LfaContext* h, int n, int H, int W, int dtype, int L, int m
     if ((rc = ensure(h->info, N * sizeof(LfaImageInfo)))) return rc;
     if ((rc = ensure(h->hist, N * hist_stride * 4))) return rc;
     if ((rc = ensure(h->edges, N * lfa::kEdges * 8))) return rc;
+    if ((rc = ensure(h->edges_i, N * lfa::kEdgesI * 4))) return rc;
     if ((rc = ensure(h->maskT, N * HB * W * 8))) return rc;
     if ((rc = ensure(h->col_cnt, N * (W + 1) * 4))) return rc;
     if ((rc = ensure(h->run_se, N * cap * 4))) return rc;
@@ -130,11 +132,13 @@ int ensure_workspace(LfaContext* h, int n, int H, int W, int dtype, int L, int m
     if ((rc = ensure(h->parent, N * cap * 4))) return rc;
     if ((rc = ensure(h->area, N * cap * 4))) return rc;
     if ((rc = ensure(h->bbox, N * cap * 16))) return rc;
-    if ((rc = ensure(h->firstbits, N * H * W64 * 8))) return rc;
-    if ((rc = ensure(h->wordrank, N * H * W64 * 4))) return rc;
+    const size_t nwp = ((size_t)H * W64 + 3) & ~(size_t)3;
+    if ((rc = ensure(h->firstbits, N * nwp * 8))) return rc;
+    if ((rc = ensure(h->wordrank, N * nwp * 4))) return rc;
     if ((rc = ensure(h->root_of_label, N * cap * 4))) return rc;
-    if ((rc = ensure(h->cand, N * cap * 4))) return rc;
-    if ((rc = ensure(h->cand_ok, N * cap))) return rc;
+    const size_t ccap = (size_t)H * W / lfa::kAreaMin + 1;
+    if ((rc = ensure(h->cand, N * ccap * 4))) return rc;
+    if ((rc = ensure(h->cand_sum, N * ccap * 3 * 8))) return rc;
     if ((rc = ensure(h->rois, N * (size_t)max_strips * sizeof(LfaRoi)))) return rc;
     return LFA_OK;
 }
@@ -158,14 +162,17 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.n = n; j.H = H; j.W = W; j.C = C; j.dtype = dtype;
     j.min_maxr = min_maxr; j.min_maxc = min_maxc; j.line_length = L;
     j.gray_variant = h->gray_variant;
+    j.debug_flags = h->debug_flags;
     j.aligned16 = (((uintptr_t)images & 15) == 0 && (j.img_bytes & 15) == 0) ? 1 : 0;
     j.HB = (H + 63) / 64; j.W64 = (W + 63) / 64;
+    j.nwp = ((int64_t)H * j.W64 + 3) & ~(int64_t)3;
     j.run_cap = run_capacity(H, W, L);
     j.max_strips = max_strips;
     j.info = (LfaImageInfo*)h->info.p;
     j.hist = (uint32_t*)h->hist.p;
     j.hist_stride = (dtype == LFA_U16) ? lfa::kHistBinsU16 : 256;
     j.edges_g = (double*)h->edges.p;
+    j.edges_i = (uint32_t*)h->edges_i.p;
     j.maskT = (uint64_t*)h->maskT.p;
     j.col_cnt = (uint32_t*)h->col_cnt.p;
     j.run_se = (uint32_t*)h->run_se.p;
@@ -176,8 +183,9 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.firstbits = (uint64_t*)h->firstbits.p;
     j.wordrank = (uint32_t*)h->wordrank.p;
     j.root_of_label = (int32_t*)h->root_of_label.p;
+    j.cand_cap = (int32_t)((int64_t)H * W / lfa::kAreaMin + 1);
     j.cand = (int32_t*)h->cand.p;
-    j.cand_ok = (uint8_t*)h->cand_ok.p;
+    j.cand_sum = (unsigned long long*)h->cand_sum.p;
     j.lut8 = (const uint8_t*)h->lut8.p;
     j.lut16 = (const uint16_t*)h->lut16.p;
     return j;
@@ -288,6 +296,12 @@ int lfa_set_gray_variant(LfaHandle h, int variant) {
     return LFA_OK;
 }
 
+int lfa_set_debug_flags(LfaHandle h, int flags) {
+    if (!h) return fail(LFA_ERR_ARG, "null handle");
+    h->debug_flags = flags;
+    return LFA_OK;
+}
+
 int lfa_detect_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
                      int line_length, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
                      void* stream) {
@@ -309,6 +323,7 @@ int lfa_profile_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
     j.images = (const uint8_t*)images;
     j.img_bytes = (int64_t)H * W * C * (dtype == LFA_U16 ? 2 : 1);
     j.n = n; j.H = H; j.W = W; j.C = C; j.dtype = dtype;
+    j.aligned16 = (((uintptr_t)images & 15) == 0 && (j.img_bytes & 15) == 0) ? 1 : 0;
     TimerScope ts(h);
     LFA_HIP(lfa::launch_profiles(j, rois, n_rois, nullptr, 0, inverse, range, out_profiles, profile_stride, out_peaks,
                                  (hipStream_t)stream));

@@ -11,6 +11,10 @@ namespace lfa {
 
 constexpr int kHistBinsU16 = 65536;
 constexpr int kEdges = 257;              // 256 float bins -> 257 edges
+constexpr int kEdgesI = 264;             // integer edge record per image: 257 thresholds + the three words below
+constexpr int kEdgesI_Crit = 257;        // != 0: some histogram edge is critical -> float64 histogram path
+constexpr int kEdgesI_MaskThr = 258;     // integer form of the mask threshold
+constexpr int kEdgesI_MaskCrit = 259;    // != 0: mask threshold critical -> float64 mask path
 constexpr int kAreaMin = 100;            // detection.py:81
 constexpr int kMaxCand = 1 << 20;
 
@@ -23,10 +27,12 @@ struct Job {
     int32_t dtype;           // LFA_U8 / LFA_U16
     int32_t min_maxr, min_maxc, line_length;
     int32_t gray_variant;
+    int32_t debug_flags;     // bit0: force the float64 colour path (as if every threshold were critical)
     int32_t aligned16;       // images base and per-image / per-row strides allow 16-byte vector loads
     // derived
     int32_t HB;              // row blocks of 64 rows
     int32_t W64;             // 64-column words per row of the first-pixel bitmap
+    int64_t nwp;             // words per image of that bitmap: H*W64 rounded up to a multiple of 4
     int32_t run_cap;         // run capacity per image
     int32_t max_strips;
     // workspace (all per image, image i at i*stride)
@@ -34,6 +40,7 @@ struct Job {
     uint32_t* hist;          // [n][65536]      (uint16)  or [n][256]
     int32_t hist_stride;
     double* edges_g;         // [n][257]  gray-space bin edges (colour path)
+    uint32_t* edges_i;       // [n][264]  the same as integer thresholds on G = 2125*b0 + 7154*b1 + 721*b2 (k_threshold.hip)
     uint64_t* maskT;         // [n][HB][W]      vertical 64-row words, thresholded image
     uint32_t* col_cnt;       // [n][W+1]        runs per column -> exclusive offsets
     uint32_t* run_se;        // [n][run_cap]    start | (end_inclusive << 16)
@@ -41,11 +48,12 @@ struct Job {
     int32_t* parent;         // [n][run_cap]
     int32_t* area;           // [n][run_cap]    valid at roots
     int32_t* bbox;           // [n][run_cap][4] minr, minc, maxr, maxc (half-open) valid at roots
-    uint64_t* firstbits;     // [n][H*W64]      bit set at the raster-first pixel of every component
-    uint32_t* wordrank;      // [n][H*W64]      exclusive prefix popcount of firstbits
+    uint64_t* firstbits;     // [n][nwp]        bit set at the raster-first pixel of every component
+    uint32_t* wordrank;      // [n][nwp]        exclusive prefix popcount of firstbits
     int32_t* root_of_label;  // [n][run_cap]
-    int32_t* cand;           // [n][run_cap]    labels (1-based) with area >= 100, ascending
-    uint8_t* cand_ok;        // [n][run_cap]    mean test passed
+    int32_t cand_cap;        // candidates per image: H*W/100 + 1 (disjoint components of >= 100 pixels)
+    int32_t* cand;           // [n][cand_cap]   labels (1-based) with area >= 100, ascending
+    unsigned long long* cand_sum;  // [n][cand_cap][3] integer sums of the original image over each candidate's box
     const uint8_t* lut8;     // [256]
     const uint16_t* lut16;   // [65536]
 };

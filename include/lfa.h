@@ -122,6 +122,10 @@ int lfa_set_gamma_lut(LfaHandle h, int dtype, const void* lut, int n);
 /* Select the rounding order of rgb2gray's matmul (LFA_GRAY_*), colorconv.py:876-877. */
 int lfa_set_gray_variant(LfaHandle h, int variant);
 
+/* Test hook (no counterpart in the reference).  bit0: colour images take the float64 compare path even when the exact
+ * integer form of the thresholds is available (that path otherwise runs only for "critical" thresholds). */
+int lfa_set_debug_flags(LfaHandle h, int flags);
+
 /* ---- detect: detect_lateral_flow_tests(image, line_length) -- detection.py:31-94 ----------------------------------- */
 
 /* images: n images of H x W x C pixels of `dtype` (C==1: 2-D input; C==3: colour, uint8 only).

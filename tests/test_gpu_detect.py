@@ -87,6 +87,34 @@ def test_synthetic_rgb(capi, eng, seed):
     assert len(d["strips"]) >= 4
 
 
+@pytest.mark.parametrize("seed", [4, 5])
+def test_colour_float64_fallback_path(capi, eng, seed):
+    """The float64 compare path (taken when a threshold is 'critical' for the integer form) must give the same answer."""
+    from image_analysis_amd.synth import synth_rgb
+    img = synth_rgb(256, 384, 6, seed)
+    mm_r, mm_c = gui_params(img)
+    eng.set_debug_flags(1)
+    try:
+        check_detect(capi, eng, img, mm_r, mm_c)
+        check_detect(capi, eng, np.ascontiguousarray(img[:75, :100]), 12, 3)       # scalar (ragged) kernels
+    finally:
+        eng.set_debug_flags(0)
+
+
+def test_colour_extreme_values(capi, eng):
+    """black and saturated pixels, all 256 levels per channel, strongly different channels"""
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, size=(128, 256, 3), dtype=np.uint8)
+    img[:40] = 0
+    img[40:90, 30:60] = 255
+    img[90:, :, 0] = 255
+    img[90:, :, 2] = 0
+    check_detect(capi, eng, img, 30, 8)
+    img2 = np.zeros((64, 64, 3), np.uint8)
+    img2[10:50, 20:30] = (255, 255, 255)
+    check_detect(capi, eng, img2, 20, 5)
+
+
 def test_synthetic_u16_small(capi, eng):
     from image_analysis_amd.synth import synth_u16
     img = synth_u16(512, 512, 10, 5)
