@@ -54,47 +54,59 @@ __device__ inline void store_peaks(LfaPeaks* dst, const TwoPeaks& t, int length)
     *dst = r;
 }
 
-// One 256-thread block per ROI.  The ROI's rows are read as aligned dwords; every (row, dword) pair is an independent
-// work item (so many loads are in flight per thread), the integer row sums are accumulated with LDS atomics, then
-// profile[r] = sum / count in float64.  Rows beyond kProfLds (or unaligned batches) take the plain path.
+// One WAVE per ROI, up to four ROIs per block (the peak search is sequential per profile, so the parallelism is across
+// ROIs; the LDS per wave is `lstride` float64 + `lstride` uint32 slots, chosen at launch from the profile stride).
+//   pooled: lfa_analyze_batch -- k_box_sums already wrote the window's integer row sums, no pixel is read here;
+//   dwords: the ROI's rows are read as aligned dwords, every (row, dword) an independent item, row sums in LDS atomics;
+//   plain:  16 lanes per row (unaligned batches, or profiles longer than the LDS slots: then the peak search reads
+//           the profile from global memory).
+// In every mode profile[r] = integer row sum / element count in float64.
 __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int n_rois, const int32_t* counts, int slots,
-                                                 int inverse, int rng, double* profiles, int stride, LfaPeaks* peaks) {
-    __shared__ double sp[kProfLds];
-    __shared__ unsigned int rs[kProfLds];
-    const int ri = blockIdx.x;
-    if (ri >= n_rois) return;
-    if (counts && (ri % slots) >= counts[ri / slots]) return;        // analyze path: slot beyond this image's strips
-    const LfaRoi roi = rois[ri];
+                                                 const int32_t* rs_off, int inverse, int rng, double* profiles, int stride,
+                                                 LfaPeaks* peaks, int lstride) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int wpb = blockDim.x >> 6;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* sp = (double*)smem + (int64_t)wv * lstride;
+    unsigned int* rs = (unsigned int*)((double*)smem + (int64_t)wpb * lstride) + (int64_t)wv * lstride;
+    const int ri = blockIdx.x * wpb + wv;
+    bool valid = ri < n_rois;
+    if (valid && counts && (ri % slots) >= counts[ri / slots]) valid = false;   // analyze path: slot beyond this image's strips
+    LfaRoi roi; roi.image = 0; roi.r0 = roi.r1 = roi.c0 = roi.c1 = 0;
+    if (valid) roi = rois[ri];
     const int len = roi.r1 - roi.r0;
-    double* prof = profiles + (int64_t)ri * stride;
-    const int t = threadIdx.x;
-    const bool bad = roi.image < 0 || roi.image >= j.n || roi.r0 < 0 || roi.r1 > j.H || roi.c0 < 0 || roi.c1 > j.W ||
-                     len < 0 || roi.c1 < roi.c0 || len > stride;
-    if (bad) {
-        if (t == 0) { LfaPeaks r; r.n_peaks = -1; r.length = len; r.start[0] = r.start[1] = r.end[0] = r.end[1] = -1;
-                      r.area[0] = r.area[1] = 0.0; peaks[ri] = r; }
-        return;
-    }
-    const uint8_t* base = j.images + (int64_t)roi.image * j.img_bytes;
+    const bool bad = valid && (roi.image < 0 || roi.image >= j.n || roi.r0 < 0 || roi.r1 > j.H || roi.c0 < 0 || roi.c1 > j.W ||
+                               len < 0 || roi.c1 < roi.c0 || len > stride);
+    const bool work = valid && !bad;
+    double* prof = profiles + (int64_t)(valid ? ri : 0) * stride;
+    const uint8_t* base = j.images + (int64_t)(work ? roi.image : 0) * j.img_bytes;
     const int C = j.C;
     const int esz = (j.dtype == LFA_U16) ? 2 : 1;
     const int ne = (roi.c1 - roi.c0) * C;                 // elements per row
     const double cnt = (double)ne;
-    const bool use_lds = len <= kProfLds;
+    const bool use_lds = lstride > 0 && len <= lstride;
     const int64_t row_bytes = (int64_t)j.W * C * esz;
-    // u8 row sums fit 32 bits for any supported width; u16 rows up to 65535 elements too (65535*65535 < 2^32)
-    if (use_lds && j.aligned16 && (row_bytes & 3) == 0 && ne > 0 && (esz == 1 || ne <= 65536)) {
-        for (int r = t; r < len; r += 256) rs[r] = 0;
-        __syncthreads();
+    const int pooled = (work && rs_off && use_lds) ? rs_off[ri] : -1;
+    // u8 row sums fit 32 bits for any supported width; u16 rows up to 65536 elements too
+    const bool dwords = work && pooled < 0 && use_lds && j.aligned16 && (row_bytes & 3) == 0 && ne > 0 && (esz == 1 || ne <= 65536);
+    if (dwords) for (int r = lane; r < len; r += 64) rs[r] = 0;
+    __syncthreads();
+    if (pooled >= 0) {
+        const uint32_t* rsum = j.rowsum + (int64_t)roi.image * j.rowsum_cap + pooled;
+        for (int r = lane; r < len; r += 64) {
+            const double m = (double)rsum[r] / cnt;
+            prof[r] = m; sp[r] = m;
+        }
+    } else if (dwords) {
         const int64_t b0 = ((int64_t)roi.r0 * j.W + roi.c0) * C * esz;       // first byte of row 0 of the ROI
         const int64_t nbytes = (int64_t)ne * esz;
         const int64_t a0 = b0 & ~(int64_t)3;                                   // row_bytes % 4 == 0: same phase on every row
         const int ndw = (int)(((b0 + nbytes + 3) & ~(int64_t)3) - a0) >> 2;    // dwords covering one row
         const int items = len * ndw;
-#pragma unroll 4
-        for (int it = t; it < items; it += 256) {
+#pragma unroll 8
+        for (int it = lane; it < items; it += 64) {
             const int r = it / ndw, d = it - r * ndw;
-            const int64_t a = a0 + 4 * (int64_t)d;                             // byte offset inside row r's line
+            const int64_t a = a0 + 4 * (int64_t)d;
             unsigned int x = *(const unsigned int*)(base + (int64_t)r * row_bytes + a);
             unsigned int vm = 0xffffffffu;
             if (a < b0) vm &= 0xffffffffu << (8 * (int)(b0 - a));
@@ -103,20 +115,18 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
             const unsigned int s = (esz == 1) ? __builtin_amdgcn_sad_u8(x, 0u, 0u) : ((x & 0xffffu) + (x >> 16));
             if (s) atomicAdd(&rs[r], s);
         }
-        __syncthreads();
-        for (int r = t; r < len; r += 256) {
-            const double m = (double)rs[r] / cnt;
-            prof[r] = m; sp[r] = m;
-        }
-    } else {
-        const int sub = t & 15, grp = t >> 4;
-        for (int r = grp; r < len; r += 16) {
-            const int64_t e0 = ((int64_t)(roi.r0 + r) * j.W + roi.c0) * C;
+    } else if (work) {
+        const int sub = lane & 15, grp = lane >> 4;
+        for (int r = grp; r < len + 3; r += 4) {            // all 16 lanes of a group stay together for the shuffles
+            const bool in = r < len;
+            const int64_t e0 = ((int64_t)(roi.r0 + (in ? r : 0)) * j.W + roi.c0) * C;
             unsigned long long s = 0;
-            if (esz == 1) { for (int k = sub; k < ne; k += 16) s += base[e0 + k]; }
-            else { const uint16_t* b16 = (const uint16_t*)base; for (int k = sub; k < ne; k += 16) s += b16[e0 + k]; }
+            if (in) {
+                if (esz == 1) { for (int k = sub; k < ne; k += 16) s += base[e0 + k]; }
+                else { const uint16_t* b16 = (const uint16_t*)base; for (int k = sub; k < ne; k += 16) s += b16[e0 + k]; }
+            }
             s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-            if (sub == 0) {
+            if (in && sub == 0) {
                 const double m = (double)s / cnt;         // ne == 0 -> 0/0 = NaN, like np.nanmean of an empty slice
                 prof[r] = m;
                 if (use_lds) sp[r] = m;
@@ -124,10 +134,21 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
         }
     }
     __syncthreads();
-    if (t >= 64) return;
+    if (dwords)
+        for (int r = lane; r < len; r += 64) {
+            const double m = (double)rs[r] / cnt;
+            prof[r] = m; sp[r] = m;
+        }
+    __syncthreads();
+    if (bad) {
+        if (lane == 0) { LfaPeaks r; r.n_peaks = -1; r.length = len; r.start[0] = r.start[1] = r.end[0] = r.end[1] = -1;
+                         r.area[0] = r.area[1] = 0.0; peaks[ri] = r; }
+        return;
+    }
+    if (!work) return;
     const double* p = use_lds ? sp : prof;
     const TwoPeaks tp = two_peaks_t(p, len, inverse != 0, rng, inverse == 0, 25, WaveArgExt());
-    if (t == 0) store_peaks(&peaks[ri], tp, len);
+    if (lane == 0) store_peaks(&peaks[ri], tp, len);
 }
 
 // analyze_peaks / the two-peak logic on caller-supplied profiles: one wave per profile
@@ -158,11 +179,18 @@ __global__ __launch_bounds__(64) void k_peaks(const double* profiles, const int3
     if (threadIdx.x == 0) store_peaks(&out[i], tp, len);
 }
 
-hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const int32_t* counts, int slots, int inverse,
-                           int rng, double* profiles, int stride, LfaPeaks* peaks, hipStream_t s) {
+hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const int32_t* counts, int slots,
+                           const int32_t* rs_off, int inverse, int rng, double* profiles, int stride, LfaPeaks* peaks,
+                           hipStream_t s) {
     if (n_rois <= 0) return hipSuccess;
-    LFA_LAUNCH("k_profile", k_profile, dim3(n_rois), dim3(256), 0, s, j, rois, n_rois, counts, slots, inverse, rng, profiles,
-                       stride, peaks);
+    // LDS per wave: 12 bytes per profile slot; up to 4 waves per block within 64 KiB; no LDS staging beyond that
+    int lstride = (stride + 1) & ~1;
+    int wpb = 4;
+    while (wpb > 1 && (size_t)wpb * lstride * 12 > 65536) wpb >>= 1;
+    if ((size_t)wpb * lstride * 12 > 65536) lstride = 0;
+    const size_t lds = (size_t)wpb * lstride * 12;
+    LFA_LAUNCH("k_profile", k_profile, dim3((n_rois + wpb - 1) / wpb), dim3(64 * wpb), lds, s, j, rois, n_rois, counts, slots,
+               rs_off, inverse, rng, profiles, stride, peaks, lstride);
     return hipGetLastError();
 }
 

@@ -4,6 +4,10 @@
 //            :118-127 (check_duplicate), :138-153 (remove_outliers), :215-216 (analysis window of a strip).
 // Means are exact integer sums followed by the reference's float64 divisions (np.mean of an integer array sums in
 // float64, which is exact below 2^53).
+//
+// The box of a candidate is exactly the crop detect returns for it, and image_analysis(crop, False) profiles a
+// window of that crop.  So while k_box_sums reads a box for the mean test it also writes the integer row sums of the
+// analysis window into a per-image pool; the profile stage of lfa_analyze_batch then needs no second read of the pixels.
 #include "lfa_internal.h"
 #include "lfa_device.h"
 
@@ -11,10 +15,25 @@ namespace lfa {
 
 constexpr int kMaxStripsLds = 1024;
 
-// labels with area >= 100, ascending, one block per image
+constexpr int kWinRowsLds = 2048;
+
+struct Box { int minr, minc, maxr, maxc;      // expanded, NOT clipped (detection.py:73-74)
+             int cr, cc; };                   // clipped ends (numpy slicing)
+
+__device__ inline Box cand_box(const Job& j, int64_t rbase, int root) {
+    const int* bb = j.bbox + (rbase + root) * 4;
+    Box b;
+    b.minr = bb[0]; b.minc = bb[1];
+    b.maxr = max(bb[2], b.minr + j.min_maxr); b.maxc = max(bb[3], b.minc + j.min_maxc);
+    b.cr = min(b.maxr, j.H); b.cc = min(b.maxc, j.W);
+    return b;
+}
+
+// labels with area >= 100, ascending, one block per image; then pool offsets for the window row sums
 __global__ __launch_bounds__(256) void k_candidates(Job j) {
     const int img = blockIdx.x;
     const int64_t rbase = (int64_t)img * j.run_cap;
+    const int64_t cbase = (int64_t)img * j.cand_cap;
     const int K = j.info[img].n_labels;
     __shared__ int wcnt[4];
     __shared__ int base;
@@ -31,54 +50,78 @@ __global__ __launch_bounds__(256) void k_candidates(Job j) {
         int offs = base;
         for (int k = 0; k < wv; ++k) offs += wcnt[k];
         if (flag) {
-            const int64_t slot = (int64_t)img * j.cand_cap + offs + __popcll(bal & ((1ull << lane) - 1ull));
+            const int64_t slot = cbase + offs + __popcll(bal & ((1ull << lane) - 1ull));
             j.cand[slot] = l + 1;
             j.cand_sum[slot * 3 + 0] = 0; j.cand_sum[slot * 3 + 1] = 0; j.cand_sum[slot * 3 + 2] = 0;
+            j.cand_rs_off[slot] = -1;
         }
         __syncthreads();
         if (t == 0) base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
         __syncthreads();
     }
-    if (t == 0) j.info[img].n_candidates = base;
+    if (t != 0) return;
+    const int nc = base;
+    j.info[img].n_candidates = nc;
+    // window row-sum pool: first come first served in label order; needs the dword path of k_box_sums
+    const int esz = (j.dtype == LFA_U16) ? 2 : 1;
+    const bool fast = j.aligned16 && ((((int64_t)j.W * j.C * esz) & 3) == 0);
+    if (!fast || j.info[img].label00 == 0) return;            // no box pass for this image (see k_box_sums): no pooled rows
+    int used = 0;
+    for (int ci = 0; ci < nc && ci < 4096; ++ci) {
+        const Box b = cand_box(j, rbase, j.root_of_label[rbase + j.cand[cbase + ci] - 1]);
+        const int h = b.cr - b.minr, w = b.cc - b.minc;
+        const int len = (int)((double)h * .6) - (int)((double)h * .25);
+        const int ne = ((int)((double)w * .7) - (int)((double)w * .3)) * j.C;
+        if (len <= 0 || len > kWinRowsLds || ne <= 0 || (esz == 2 && ne > 65536)) continue;
+        if (used + len > j.rowsum_cap) break;
+        j.cand_rs_off[cbase + ci] = used;
+        used += len;
+    }
 }
 
 // Integer sums of the ORIGINAL image over the expanded, clipped box of every candidate (per channel for colour).
-// A box is cut into slices of 64 rows; every (candidate, slice) is one work item of one block, so a tall strip is
-// summed by ~16 blocks at once instead of one block walking 1000 rows.  Rows are read as aligned dwords (a row of a
-// strip is ~170 bytes): the channel of a byte is its offset in the image modulo 3.
+// One block per candidate.  Rows are read as aligned dwords (a row of a strip is ~170 bytes) and every (row, dword)
+// of the box is an independent item, so each thread keeps several loads in flight; the channel of a byte is its offset
+// in the image modulo 3.  The rows of the analysis window are also summed (all channels together) into LDS and
+// written to the row-sum pool.
 __global__ __launch_bounds__(256) void k_box_sums(Job j) {
     const int img = blockIdx.y;
     const int64_t rbase = (int64_t)img * j.run_cap;
     const int64_t cbase = (int64_t)img * j.cand_cap;
+    // The sums feed only the test `mean(box) > labeled[0,0]` (detection.py:67, :81).  When pixel (0,0) is background that
+    // is `mean > 0`, which always holds: the box contains the component, and every pixel of a component is above a
+    // non-negative threshold, hence non-zero.  So the box pass runs only for images whose corner pixel is foreground.
+    if (j.info[img].label00 == 0) return;
     const int nc = j.info[img].n_candidates;
     const uint8_t* base = j.images + (int64_t)img * j.img_bytes;
     __shared__ unsigned long long part[4][3];
+    __shared__ unsigned int wrow[kWinRowsLds];                    // window row sums of this candidate
     const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
     const int esz = (j.dtype == LFA_U16) ? 2 : 1;
     const int64_t pxb = (int64_t)esz * j.C;                       // bytes per pixel
-    const int HB = j.HB;
-    const bool dwords = j.aligned16 != 0;
-    for (int wi = blockIdx.x; wi < nc * HB; wi += gridDim.x) {
-        const int ci = wi / HB, sl = wi - ci * HB;
-        const int root = j.root_of_label[rbase + j.cand[cbase + ci] - 1];
-        const int* bb = j.bbox + (rbase + root) * 4;
-        const int minr = bb[0], minc = bb[1];
-        int maxr = max(bb[2], minr + j.min_maxr), maxc = max(bb[3], minc + j.min_maxc);
-        maxr = min(maxr, j.H); maxc = min(maxc, j.W);
-        const int r0 = minr + sl * 64;
-        if (r0 >= maxr) continue;                                 // uniform for the block
-        const int r1 = min(maxr, r0 + 64);
-        unsigned int s0 = 0, s1 = 0, s2 = 0;
-        if (dwords && (((int64_t)j.W * pxb) & 3) == 0) {
-            // every (row, dword) of the slice is an independent item: several loads in flight per thread
-            const int64_t row_bytes = (int64_t)j.W * pxb;
-            const int64_t b0 = ((int64_t)r0 * j.W + minc) * pxb;              // first byte of the slice's first row
-            const int64_t nbytes = (int64_t)(maxc - minc) * pxb;
+    const int64_t row_bytes = (int64_t)j.W * pxb;
+    const bool dwords = j.aligned16 != 0 && (row_bytes & 3) == 0;
+    for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
+        const Box bx = cand_box(j, rbase, j.root_of_label[rbase + j.cand[cbase + ci] - 1]);
+        const int minr = bx.minr, minc = bx.minc, maxr = bx.cr, maxc = bx.cc;
+        unsigned long long s0 = 0, s1 = 0, s2 = 0;
+        if (dwords) {
+            const int rs_off = j.cand_rs_off[cbase + ci];
+            const int h = maxr - minr, w = maxc - minc;
+            const int wr0 = (int)((double)h * .25), wr1 = (int)((double)h * .6);    // window rows, relative to minr
+            const int64_t b0 = ((int64_t)minr * j.W + minc) * pxb;            // first byte of the box's first row
+            const int64_t nbytes = (int64_t)w * pxb;
+            const int64_t bw0 = b0 + (int64_t)((int)((double)w * .3)) * pxb;  // window bytes of that row
+            const int64_t bw1 = b0 + (int64_t)((int)((double)w * .7)) * pxb;
+            const bool want_rows = rs_off >= 0;
+            if (want_rows) { for (int k = t; k < wr1 - wr0; k += 256) wrow[k] = 0; __syncthreads(); }
             const int64_t a0 = b0 & ~(int64_t)3;                               // row_bytes % 4 == 0: same phase on every row
             const int ndw = (int)(((b0 + nbytes + 3) & ~(int64_t)3) - a0) >> 2;
-            const int items = (r1 - r0) * ndw;
+            const int items = h * ndw;
             const int ph0 = (int)(a0 % 3);                                     // row_bytes % 3 == 0 for colour: same on every row
-#pragma unroll 4
+            unsigned int u0 = 0, u1 = 0, u2 = 0;
+            int flush = 0;
+#pragma unroll 8
             for (int it = t; it < items; it += 256) {
                 const int rr = it / ndw, d = it - rr * ndw;
                 const int64_t a = a0 + 4 * (int64_t)d;
@@ -92,17 +135,32 @@ __global__ __launch_bounds__(256) void k_box_sums(Job j) {
                     const unsigned int m0 = ph == 0 ? 0xff0000ffu : (ph == 1 ? 0x00ff0000u : 0x0000ff00u);
                     const unsigned int m1 = ph == 0 ? 0x0000ff00u : (ph == 1 ? 0xff0000ffu : 0x00ff0000u);
                     const unsigned int m2 = ph == 0 ? 0x00ff0000u : (ph == 1 ? 0x0000ff00u : 0xff0000ffu);
-                    s0 = __builtin_amdgcn_sad_u8(x & m0, 0u, s0);
-                    s1 = __builtin_amdgcn_sad_u8(x & m1, 0u, s1);
-                    s2 = __builtin_amdgcn_sad_u8(x & m2, 0u, s2);
+                    u0 = __builtin_amdgcn_sad_u8(x & m0, 0u, u0);
+                    u1 = __builtin_amdgcn_sad_u8(x & m1, 0u, u1);
+                    u2 = __builtin_amdgcn_sad_u8(x & m2, 0u, u2);
                 } else if (esz == 1) {
-                    s0 = __builtin_amdgcn_sad_u8(x, 0u, s0);
+                    u0 = __builtin_amdgcn_sad_u8(x, 0u, u0);
                 } else {
-                    s0 += (x & 0xffffu) + (x >> 16);
+                    u0 += (x & 0xffffu) + (x >> 16);
+                }
+                if (++flush == 8192) { s0 += u0; s1 += u1; s2 += u2; u0 = u1 = u2 = 0; flush = 0; }   // keep 32-bit partials exact
+                if (want_rows && rr >= wr0 && rr < wr1 && a + 4 > bw0 && a < bw1) {
+                    unsigned int wm = 0xffffffffu;
+                    if (a < bw0) wm &= 0xffffffffu << (8 * (int)(bw0 - a));
+                    if (a + 4 > bw1) wm &= 0xffffffffu >> (8 * (int)(a + 4 - bw1));
+                    const unsigned int y = x & wm;
+                    const unsigned int sw = (esz == 1) ? __builtin_amdgcn_sad_u8(y, 0u, 0u) : ((y & 0xffffu) + (y >> 16));
+                    if (sw) atomicAdd(&wrow[rr - wr0], sw);
                 }
             }
+            s0 += u0; s1 += u1; s2 += u2;
+            if (want_rows) {
+                __syncthreads();
+                uint32_t* dst = j.rowsum + (int64_t)img * j.rowsum_cap + rs_off;
+                for (int k = t; k < wr1 - wr0; k += 256) dst[k] = wrow[k];
+            }
         } else {
-            for (int r = r0 + wv; r < r1; r += 4) {
+            for (int r = minr + wv; r < maxr; r += 4) {
                 const int64_t rowpx = (int64_t)r * j.W;
                 for (int c = minc + lane; c < maxc; c += 64) {
                     const int64_t px = rowpx + c;
@@ -115,15 +173,12 @@ __global__ __launch_bounds__(256) void k_box_sums(Job j) {
         const unsigned long long w0 = wave_sum_u64(s0), w1 = wave_sum_u64(s1), w2 = wave_sum_u64(s2);
         if (lane == 0) { part[wv][0] = w0; part[wv][1] = w1; part[wv][2] = w2; }
         __syncthreads();
-        if (t < 3) {
-            const unsigned long long v = part[0][t] + part[1][t] + part[2][t] + part[3][t];
-            if (v) atomicAdd(&j.cand_sum[(cbase + ci) * 3 + t], v);
-        }
+        if (t < 3) j.cand_sum[(cbase + ci) * 3 + t] = part[0][t] + part[1][t] + part[2][t] + part[3][t];
         __syncthreads();
     }
 }
 
-struct Acc { int minr, maxr, minc, maxc, area, label; };
+struct Acc { int minr, maxr, minc, maxc, area, label, rs_off; };
 
 // one wave per image: accept in label order with the inclusive-overlap test, drop wide outliers, stable sort
 __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
@@ -142,11 +197,11 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
     for (int ci = 0; ci < nc; ++ci) {                         // uniform: every lane walks the same candidates
         const int lab = j.cand[cbase + ci];
         const int root = j.root_of_label[rbase + lab - 1];
-        const int* bb = j.bbox + (rbase + root) * 4;
-        const int minr = bb[0], minc = bb[1];
-        const int maxr = max(bb[2], minr + j.min_maxr), maxc = max(bb[3], minc + j.min_maxc);
-        {   // np.mean of the clipped box (detection.py:76-81): exact integer sums, then the reference's divisions
-            const double cnt = (double)((long long)(min(maxr, j.H) - minr) * (long long)(min(maxc, j.W) - minc));
+        const Box bx = cand_box(j, rbase, root);
+        const int minr = bx.minr, minc = bx.minc, maxr = bx.maxr, maxc = bx.maxc;
+        if (inf->label00 != 0) {   // np.mean of the clipped box (detection.py:76-81); always > 0 when the corner is background
+            // exact integer sums, then the reference's divisions
+            const double cnt = (double)((long long)(bx.cr - minr) * (long long)(bx.cc - minc));
             const unsigned long long* cs = j.cand_sum + (cbase + ci) * 3;
             double m;
             if (j.C == 3) {
@@ -166,7 +221,7 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
         if (na < cap) {
             if (lane == 0) {
                 Acc a; a.minr = minr; a.maxr = maxr; a.minc = minc; a.maxc = maxc;
-                a.area = j.area[rbase + root]; a.label = lab;
+                a.area = j.area[rbase + root]; a.label = lab; a.rs_off = j.cand_rs_off[cbase + ci];
                 acc[na] = a;
             }
             __syncthreads();
@@ -214,6 +269,7 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
             r.r0 = a.minr + (int)((double)h * .25); r.r1 = a.minr + (int)((double)h * .6);
             r.c0 = a.minc + (int)((double)w * .3);  r.c1 = a.minc + (int)((double)w * .7);
             rois[rank] = r;
+            j.slot_rs_off[(int64_t)img * j.max_strips + rank] = a.rs_off;
         }
     }
     if (lane == 0) {
@@ -225,9 +281,9 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
 
 hipError_t launch_regions(const Job& j, const OutPtrs& o, hipStream_t s) {
     LFA_LAUNCH("k_candidates", k_candidates, dim3(j.n), dim3(256), 0, s, j);
-    int gx = (16384 + j.n - 1) / j.n;
+    int gx = (8192 + j.n - 1) / j.n;                       // one block per candidate; blocks loop when there are more
     if (gx < 16) gx = 16;
-    if (gx > 1024) gx = 1024;
+    if (gx > 256) gx = 256;
     LFA_LAUNCH("k_box_sums", k_box_sums, dim3(gx, j.n), dim3(256), 0, s, j);
     LFA_LAUNCH("k_finalize", k_finalize, dim3(j.n), dim3(64), 0, s, j, o);
     return hipGetLastError();

@@ -300,17 +300,30 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     const float scalef = 256.0f / ((float)j.info[img].vmax - vminf);
     const uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
     const bool integer_path = eg[kEdgesI_Crit] == 0;
-    __shared__ uint32_t sg[kEdges + 1];
+    __shared__ uint32_t sg[kEdges + 3];
+    __shared__ uint8_t tab[2496];                          // bin of G = b << 10, b = 0 .. 2490 (G <= 2 550 000)
     if (integer_path) {
-        for (int k = threadIdx.x; k < kEdges; k += 256) sg[k] = eg[k];
+        for (int k = threadIdx.x; k < kEdges + 3; k += 256) sg[k] = (k < 256) ? eg[k] : kGInf;   // sentinel above bin 255
+        __syncthreads();
+        for (int b = threadIdx.x; b < 2496; b += 256) {
+            const uint32_t G0 = (uint32_t)b << 10;
+            int lo = 0, hi = 255;                           // largest k with sg[k] <= G0  (sg[0] = 0)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int mid = (lo + hi + 1) >> 1;
+                const bool ge = sg[mid] <= G0;
+                lo = ge ? mid : lo;
+                hi = ge ? hi : mid - 1;
+            }
+            tab[b] = (uint8_t)lo;
+        }
         __syncthreads();
     }
     auto addG = [&](uint32_t G) {                          // integer path: see g_threshold
-        const float vf = __builtin_amdgcn_exp2f(0.4f * __builtin_amdgcn_logf((float)G * (1.0f / 2550000.0f)));
-        int k = (int)((vf - vminf) * scalef);
-        k = k < 0 ? 0 : (k > 255 ? 255 : k);
-        while (k > 0 && G < sg[k]) --k;                     // largest k in [0,255] with Gt[k] <= G  (Gt[0] = 0)
-        while (k < 255 && G >= sg[k + 1]) ++k;
+        int k = tab[G >> 10];                               // bin of the bucket start: a lower bound
+        k += (G >= sg[k + 1]) ? 1 : 0;
+        k += (G >= sg[k + 1]) ? 1 : 0;
+        while (G >= sg[k + 1]) ++k;                         // dark pixels: bins narrower than a bucket (sg[256] = inf ends it)
         atomicAdd(&sh[k * kCopies + cp], 1u);
     };
     auto add = [&](double g) {                             // float64 path (an edge is critical): exact compares + census

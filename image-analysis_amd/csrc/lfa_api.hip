@@ -79,13 +79,13 @@ struct LfaContext {
     int gray_variant = LFA_GRAY_FMA_102;
     int debug_flags = 0;
     Buf info, hist, edges, edges_i, maskT, col_cnt, run_se, run_col, parent, area, bbox, firstbits, wordrank, root_of_label, cand,
-        cand_sum, lut8, lut16, rois;
+        cand_sum, cand_rs_off, rowsum, slot_rs_off, lut8, lut16, rois;
     lfa::Job last{};
     bool have_last = false;
     EventTimer* timer = nullptr;
     std::vector<Buf*> all() {
         return {&info, &hist, &edges, &edges_i, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &firstbits, &wordrank,
-                &root_of_label, &cand, &cand_sum, &lut8, &lut16, &rois};
+                &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &lut8, &lut16, &rois};
     }
 };
 
@@ -139,6 +139,9 @@ int ensure_workspace(LfaContext* h, int n, int H, int W, int dtype, int L, int m
     const size_t ccap = (size_t)H * W / lfa::kAreaMin + 1;
     if ((rc = ensure(h->cand, N * ccap * 4))) return rc;
     if ((rc = ensure(h->cand_sum, N * ccap * 3 * 8))) return rc;
+    if ((rc = ensure(h->cand_rs_off, N * ccap * 4))) return rc;
+    if ((rc = ensure(h->rowsum, N * (size_t)16 * H * 4))) return rc;
+    if ((rc = ensure(h->slot_rs_off, N * (size_t)max_strips * 4))) return rc;
     if ((rc = ensure(h->rois, N * (size_t)max_strips * sizeof(LfaRoi)))) return rc;
     return LFA_OK;
 }
@@ -186,6 +189,10 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.cand_cap = (int32_t)((int64_t)H * W / lfa::kAreaMin + 1);
     j.cand = (int32_t*)h->cand.p;
     j.cand_sum = (unsigned long long*)h->cand_sum.p;
+    j.cand_rs_off = (int32_t*)h->cand_rs_off.p;
+    j.rowsum = (uint32_t*)h->rowsum.p;
+    j.rowsum_cap = 16 * H;
+    j.slot_rs_off = (int32_t*)h->slot_rs_off.p;
     j.lut8 = (const uint8_t*)h->lut8.p;
     j.lut16 = (const uint16_t*)h->lut16.p;
     return j;
@@ -325,7 +332,7 @@ int lfa_profile_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
     j.n = n; j.H = H; j.W = W; j.C = C; j.dtype = dtype;
     j.aligned16 = (((uintptr_t)images & 15) == 0 && (j.img_bytes & 15) == 0) ? 1 : 0;
     TimerScope ts(h);
-    LFA_HIP(lfa::launch_profiles(j, rois, n_rois, nullptr, 0, inverse, range, out_profiles, profile_stride, out_peaks,
+    LFA_HIP(lfa::launch_profiles(j, rois, n_rois, nullptr, 0, nullptr, inverse, range, out_profiles, profile_stride, out_peaks,
                                  (hipStream_t)stream));
     return LFA_OK;
 }
@@ -363,7 +370,7 @@ int lfa_analyze_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
                      out_info, out_rois, (hipStream_t)stream, &j);
     if (rc) return rc;
     TimerScope ts(h);
-    LFA_HIP(lfa::launch_profiles(j, out_rois, n * max_strips, out_counts, max_strips, 0, 15, out_profiles, profile_stride,
+    LFA_HIP(lfa::launch_profiles(j, out_rois, n * max_strips, out_counts, max_strips, j.slot_rs_off, 0, 15, out_profiles, profile_stride,
                                  out_peaks, (hipStream_t)stream));
     return LFA_OK;
 }

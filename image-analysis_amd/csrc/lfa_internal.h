@@ -54,6 +54,10 @@ struct Job {
     int32_t cand_cap;        // candidates per image: H*W/100 + 1 (disjoint components of >= 100 pixels)
     int32_t* cand;           // [n][cand_cap]   labels (1-based) with area >= 100, ascending
     unsigned long long* cand_sum;  // [n][cand_cap][3] integer sums of the original image over each candidate's box
+    int32_t* cand_rs_off;    // [n][cand_cap]   offset of the candidate's window row sums in `rowsum`, or -1
+    uint32_t* rowsum;        // [n][rowsum_cap] integer row sums of analysis windows (written by k_box_sums)
+    int32_t rowsum_cap;      // 16 * H
+    int32_t* slot_rs_off;    // [n][max_strips] the same offset per output strip slot (written by k_finalize)
     const uint8_t* lut8;     // [256]
     const uint16_t* lut16;   // [65536]
 };
@@ -87,8 +91,8 @@ hipError_t launch_mask(const Job& j, hipStream_t s);                      // thr
 hipError_t launch_label(const Job& j, hipStream_t s);                     // opening + runs + union-find + ranks
 hipError_t launch_regions(const Job& j, const OutPtrs& o, hipStream_t s); // candidates, box means, accept, sort
 hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const int32_t* counts_or_null,
-                           int max_strips_or_0, int inverse, int rng, double* profiles, int stride, LfaPeaks* peaks,
-                           hipStream_t s);
+                           int max_strips_or_0, const int32_t* rs_off_or_null, int inverse, int rng, double* profiles,
+                           int stride, LfaPeaks* peaks, hipStream_t s);
 hipError_t launch_peaks(const double* profiles, const int32_t* lengths, int n, int stride, int inverse, int window,
                         int two, int rng, LfaPeaks* out, hipStream_t s);
 hipError_t launch_gaussian_w(const Job& j, const double* w, int radius, void* out, int out_f32, hipStream_t s);

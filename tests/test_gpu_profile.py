@@ -114,6 +114,81 @@ def test_analyze_batch_end_to_end():
         eng.close()
 
 
+def _check_analyze(eng, imgs, mm_r, mm_c):
+    res, info = eng.analyze(imgs, mm_r, mm_c, max_strips=256)
+    total = 0
+    for i, (strips, profiles, peaks) in enumerate(res):
+        d = O.detect_debug(imgs[i], mm_r, mm_c)
+        assert [[int(s["minr"]), int(s["maxr"]), int(s["minc"]), int(s["maxc"])] for s in strips] == d["strips"]
+        for k, (a, b, c, e) in enumerate(d["strips"]):
+            crop = imgs[i][a:b, c:e]
+            h = crop.shape[0]
+            if int(h * .6) - int(h * .25) <= 0:
+                assert peaks[k]["n_peaks"] == 0
+                continue
+            wp, wk = O.image_analysis(crop, False)
+            assert np.array_equal(profiles[k], wp, equal_nan=True)
+            assert peaks[k]["n_peaks"] == len(wk)
+            for q, (s0, e0, a0) in enumerate(wk):
+                assert (peaks[k]["start"][q], peaks[k]["end"][q]) == (s0, e0)
+                assert peaks[k]["area"][q] == a0 or (np.isnan(a0) and np.isnan(peaks[k]["area"][q]))
+            total += 1
+    return total, info
+
+
+@pytest.mark.parametrize("dtype,c", [(np.uint8, 0), (np.uint8, 3), (np.uint16, 0)])
+def test_analyze_many_candidates_overflow_the_row_sum_pool(dtype, c):
+    """More strips than the window row-sum pool (16*H entries) holds: later strips take the pixel path; boxes are clipped
+    by the image at the bottom and the right."""
+    import image_analysis_amd._capi as capi
+    rng = np.random.default_rng(3)
+    H, W = 160, 1024
+    img = rng.integers(5, 30, size=(H, W)).astype(np.float64)
+    for k in range(100):
+        r0 = int(rng.integers(0, H - 14)); c0 = 4 + 10 * k
+        img[r0:r0 + 12, c0:c0 + 9] = 200 + rng.integers(0, 40, size=(12, 9))
+    hi = 255 if dtype == np.uint8 else 4000
+    img = np.clip(img * (hi / 255.0), 0, hi).astype(dtype)
+    if c:
+        img = np.stack([img, np.clip(img.astype(int) + 3, 0, hi).astype(dtype), np.clip(img.astype(int) - 2, 0, hi).astype(dtype)], axis=2)
+    eng = capi.Engine(device=0, max_h=H, max_w=W, max_batch=2)
+    total, info = _check_analyze(eng, np.stack([img, img[::-1].copy()]), H, 3)
+    assert total > 100 and info["n_candidates"].min() >= 60
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype,c", [(np.uint8, 0), (np.uint8, 3), (np.uint16, 0)])
+def test_analyze_with_foreground_corner_uses_box_means(dtype, c):
+    """labeled[0,0] != 0: the mean test compares against 1.0, so box sums matter (and the window rows come from the pool)."""
+    import image_analysis_amd._capi as capi
+    rng = np.random.default_rng(8)
+    H, W = 256, 512
+    hi = 255 if dtype == np.uint8 else 3000
+    img = rng.integers(0, 3, size=(H, W)).astype(np.int64)            # background mean ~1: boxes hover around the test value
+    img[0:30, 0:40] = hi                                              # component at the origin -> label 1 at (0,0)
+    for k in range(9):
+        c0 = 60 + 48 * k
+        img[40 + 5 * k:40 + 5 * k + 150, c0:c0 + 14] = hi - 20 * k
+    img[200:212, 300:309] = hi // 2                                   # small bright blob in a dark, wide box
+    img = img.astype(dtype)
+    if c:
+        img = np.stack([img, (img // 2).astype(dtype), (img // 3).astype(dtype)], axis=2)
+    eng = capi.Engine(device=0, max_h=H, max_w=W, max_batch=1)
+    total, info = _check_analyze(eng, img[None], 200, 12)
+    assert info["label00"][0] == 1 and total >= 5
+    eng.close()
+
+
+def test_analyze_unaligned_width_takes_the_pixel_path():
+    import image_analysis_amd._capi as capi
+    from image_analysis_amd.synth import synth_rgb
+    img = np.ascontiguousarray(synth_rgb(300, 401, 5, 21)[:, :397])
+    eng = capi.Engine(device=0, max_h=300, max_w=400, max_batch=1)
+    total, _ = _check_analyze(eng, img[None], 180, 9)
+    assert total >= 3
+    eng.close()
+
+
 @pytest.mark.parametrize("shape,dtype", [((200, 300), np.uint8), ((130, 97), np.uint16), ((96, 140, 3), np.uint8),
                                           ((5, 7), np.uint8), ((300, 33, 3), np.uint8)])
 def test_gaussian_matches_scipy(det, shape, dtype):
