@@ -47,54 +47,42 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
             const int64_t px_bytes = (MODE == 2) ? 3 : (MODE == 1 ? 2 : 1);
             const uint8_t* p = base + ((int64_t)r0 * W + (int64_t)cg * 16) * px_bytes;
             const int64_t row_bytes = (int64_t)W * px_bytes;
-            auto row_bits = [&](const uint8_t* q) -> uint32_t {
-                uint32_t bits = 0;
+            // one row of 16 pixels: compare and drop the result into bit `rbit` of the 16 column words
+            auto row = [&](const uint8_t* q, uint32_t (&acc)[16], uint32_t rbit) {
                 if (MODE == 0) {
                     const uint4 a = *(const uint4*)q;
                     const uint32_t w[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) bits |= ((int)byte_of(w, k) > x_thr ? 1u : 0u) << k;
+                    for (int k = 0; k < 16; ++k) acc[k] |= ((int)byte_of(w, k) > x_thr) ? rbit : 0u;
                 } else if (MODE == 1) {
                     const uint4 a = ((const uint4*)q)[0], b = ((const uint4*)q)[1];
                     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
                         const int x = (int)((w[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
-                        bits |= (x > x_thr ? 1u : 0u) << k;
+                        acc[k] |= (x > x_thr) ? rbit : 0u;
                     }
                 } else {
                     uint32_t w[12];
                     load48(q, w);
                     if (integer_path) {
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            const uint32_t G = 2125u * byte_of(w, 3 * k) + 7154u * byte_of(w, 3 * k + 1) + 721u * byte_of(w, 3 * k + 2);
-                            bits |= (G >= G_thr ? 1u : 0u) << k;
-                        }
+                        for (int k = 0; k < 16; ++k) acc[k] |= (gray_G16(w, k) >= G_thr) ? rbit : 0u;
                     } else {
 #pragma unroll
                         for (int k = 0; k < 16; ++k) {
                             const double g = gray_u8<V>(byte_of(w, 3 * k), byte_of(w, 3 * k + 1), byte_of(w, 3 * k + 2));
-                            bits |= (g > g_thr ? 1u : 0u) << k;
+                            acc[k] |= (g > g_thr) ? rbit : 0u;
                             amb += near_rel(g, g_next) ? 1u : 0u;
                         }
                     }
                 }
-                return bits;
             };
             const int rows_lo = min(rows, 32);
 #pragma unroll 2
-            for (int r = 0; r < rows_lo; ++r) {
-                const uint32_t bits = row_bits(p + (int64_t)r * row_bytes);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) lo[k] |= ((bits >> k) & 1u) << r;
-            }
+            for (int r = 0; r < rows_lo; ++r) row(p + (int64_t)r * row_bytes, lo, 1u << r);
 #pragma unroll 2
-            for (int r = 32; r < rows; ++r) {
-                const uint32_t bits = row_bits(p + (int64_t)r * row_bytes);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) hi[k] |= ((bits >> k) & 1u) << (r - 32);
-            }
+            for (int r = 32; r < rows; ++r) row(p + (int64_t)r * row_bytes, hi, 1u << (r - 32));
             uint64_t* o = out + (int64_t)rb * W + cg * 16;
 #pragma unroll
             for (int k = 0; k < 16; k += 2) {

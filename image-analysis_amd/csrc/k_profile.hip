@@ -103,17 +103,31 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
         const int64_t a0 = b0 & ~(int64_t)3;                                   // row_bytes % 4 == 0: same phase on every row
         const int ndw = (int)(((b0 + nbytes + 3) & ~(int64_t)3) - a0) >> 2;    // dwords covering one row
         const int items = len * ndw;
-#pragma unroll 8
-        for (int it = lane; it < items; it += 64) {
-            const int r = it / ndw, d = it - r * ndw;
-            const int64_t a = a0 + 4 * (int64_t)d;
-            unsigned int x = *(const unsigned int*)(base + (int64_t)r * row_bytes + a);
-            unsigned int vm = 0xffffffffu;
-            if (a < b0) vm &= 0xffffffffu << (8 * (int)(b0 - a));
-            if (a + 4 > b0 + nbytes) vm &= 0xffffffffu >> (8 * (int)(a + 4 - (b0 + nbytes)));
-            x &= vm;
-            const unsigned int s = (esz == 1) ? __builtin_amdgcn_sad_u8(x, 0u, 0u) : ((x & 0xffffu) + (x >> 16));
-            if (s) atomicAdd(&rs[r], s);
+        // eight independent loads per lane are issued before any of them is used (the loop is latency-bound otherwise);
+        // (row, dword) of item `it` advance by 64 items per step without a division
+        const int q64 = 64 / ndw, m64 = 64 - q64 * ndw;
+        int r = lane / ndw, d = lane - r * ndw;
+        for (int it0 = lane; it0 < items; it0 += 64 * 8) {
+            unsigned int x[8];
+            int rr[8], dd[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                rr[u] = r; dd[u] = d;
+                x[u] = (it0 + 64 * u < items) ? *(const unsigned int*)(base + (int64_t)r * row_bytes + a0 + 4 * (int64_t)d) : 0u;
+                r += q64; d += m64;
+                if (d >= ndw) { d -= ndw; ++r; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (it0 + 64 * u >= items) break;
+                const int64_t a = a0 + 4 * (int64_t)dd[u];
+                unsigned int vm = 0xffffffffu;
+                if (a < b0) vm &= 0xffffffffu << (8 * (int)(b0 - a));
+                if (a + 4 > b0 + nbytes) vm &= 0xffffffffu >> (8 * (int)(a + 4 - (b0 + nbytes)));
+                const unsigned int y = x[u] & vm;
+                const unsigned int sv = (esz == 1) ? __builtin_amdgcn_sad_u8(y, 0u, 0u) : ((y & 0xffffu) + (y >> 16));
+                if (sv) atomicAdd(&rs[rr[u]], sv);
+            }
         }
     } else if (work) {
         const int sub = lane & 15, grp = lane >> 4;

@@ -321,9 +321,10 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     }
     auto addG = [&](uint32_t G) {                          // integer path: see g_threshold
         int k = tab[G >> 10];                               // bin of the bucket start: a lower bound
-        k += (G >= sg[k + 1]) ? 1 : 0;
-        k += (G >= sg[k + 1]) ? 1 : 0;
-        while (G >= sg[k + 1]) ++k;                         // dark pixels: bins narrower than a bucket (sg[256] = inf ends it)
+        const uint32_t e1 = sg[k + 1], e2 = sg[k + 2];      // one LDS access for the two next edges
+        k += (G >= e1) ? 1 : 0;
+        k += (G >= e2) ? 1 : 0;
+        if (G >= e2) { while (G >= sg[k + 1]) ++k; }        // dark pixels: bins narrower than a bucket (sg[256..] = inf ends it)
         atomicAdd(&sh[k * kCopies + cp], 1u);
     };
     auto add = [&](double g) {                             // float64 path (an edge is critical): exact compares + census
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
                 uint32_t w[12];
                 load48(base + g * 48, w);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) addG(gray_G(byte_of(w, 3 * k), byte_of(w, 3 * k + 1), byte_of(w, 3 * k + 2)));
+                for (int k = 0; k < 16; ++k) addG(gray_G16(w, k));
             }
             done = ng << 4;
         }
