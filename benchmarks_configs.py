@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's bench line): BASELINE.json configs[2] (16-bit frames), configs[4] (dense
+select-region ROIs) and the Gaussian stage, each with per-kernel times and GB/s against its algorithmic bytes.
+    python benchmarks_configs.py [u16|rois|gauss] ..."""
+import importlib
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __import__("os").path.dirname(__file__) or ".")
+capi = importlib.import_module("image_analysis_amd._capi")
+synth = importlib.import_module("image_analysis_amd.synth")
+import ctypes as C
+
+dev = torch.device("cuda", 0)
+
+
+def timed(fn, steps=3):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def bench_u16(B=512, CH=256, pool=8):
+    H = W = 2048
+    pool_np = np.stack([synth.synth_u16(H, W, 40, 1234 + i) for i in range(pool)])
+    p = torch.from_numpy(pool_np.view(np.uint8).reshape(pool, -1)).to(dev)
+    batch = p[torch.arange(B, device=dev) % pool].contiguous()
+    ms, stride = 64, int(H * .6) + 1
+    eng = capi.Engine(device=0, max_h=H, max_w=W, max_c=1, max_batch=CH)
+    strips = capi.dev_bytes(B * ms * 24, dev); counts = torch.zeros(B, dtype=torch.int32, device=dev)
+    info = capi.dev_bytes(B * 104, dev); rois = capi.dev_bytes(B * ms * 20, dev)
+    prof = torch.empty(B * ms * stride, dtype=torch.float64, device=dev); peaks = capi.dev_bytes(B * ms * 40, dev)
+    st = capi.current_stream_ptr(dev)
+    ib = H * W * 2
+
+    def step():
+        for b0 in range(0, B, CH):
+            capi._check(capi.lib.lfa_analyze_batch(eng._h, batch.data_ptr() + b0 * ib, capi.LFA_U16, CH, H, W, 1, 1020, 51, 10,
+                        strips.data_ptr() + b0 * ms * 24, ms, counts.data_ptr() + b0 * 4, info.data_ptr() + b0 * 104,
+                        rois.data_ptr() + b0 * ms * 20, prof.data_ptr() + b0 * ms * stride * 8, stride,
+                        peaks.data_ptr() + b0 * ms * 40, st))
+    dt = timed(step)
+    eng.timing("*"); step(); torch.cuda.synchronize(); kt = eng.timing_read(); eng.timing(None)
+    ns = int(counts.sum().item())
+    inf = capi.from_device(info, capi.INFO_DT, B)
+    print(json.dumps({"config": "configs[2] 2048x2048 uint16 frames", "frames": B, "ms_per_step": round(dt * 1e3, 3),
+                      "frames_per_s": round(B / dt, 1), "strips_per_s": round(ns / dt, 1), "labels_mean": float(inf["n_labels"].mean()),
+                      "e2e_frac_hbm": round(B / dt * ib / 8e12, 4),
+                      "kernel_ms": {k: round(v[0], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}}))
+    eng.close()
+
+
+def bench_rois(B=64, per=256):
+    H, W = 1536, 2048
+    pool_np = np.stack([synth.synth_rgb(H, W, 8, 1234 + i) for i in range(8)])
+    p = torch.from_numpy(pool_np.reshape(8, -1)).to(dev)
+    batch = p[torch.arange(B, device=dev) % 8].contiguous()
+    rois = synth.synth_rois(B, H, W, per).astype(capi.ROI_DT)
+    rt = capi.to_device(rois, dev)
+    n = len(rois)
+    stride = 512
+    eng = capi.Engine(device=0, max_h=H, max_w=W, max_c=3, max_batch=B)
+    prof = torch.empty(n * stride, dtype=torch.float64, device=dev); peaks = capi.dev_bytes(n * 40, dev)
+    st = capi.current_stream_ptr(dev)
+
+    def step():
+        capi._check(capi.lib.lfa_profile_batch(eng._h, batch.data_ptr(), capi.LFA_U8, B, H, W, 3, rt.data_ptr(), n, 0, 15,
+                                               prof.data_ptr(), stride, peaks.data_ptr(), st))
+    dt = timed(step)
+    byts = int(((rois["r1"] - rois["r0"]).astype(np.int64) * (rois["c1"] - rois["c0"]) * 3).sum())
+    print(json.dumps({"config": "configs[4] dense select-region: 256 ROIs/image", "images": B, "rois": n,
+                      "ms_per_step": round(dt * 1e3, 3), "rois_per_s": round(n / dt, 1), "window_bytes": byts,
+                      "GBps_algorithmic": round(byts / dt / 1e9, 1), "frac_hbm": round(byts / dt / 8e12, 4)}))
+    eng.close()
+
+
+def bench_gauss(B=64):
+    for (H, W, Cc, dt_np, f32) in ((1536, 2048, 3, np.uint8, 0), (2048, 2048, 1, np.uint16, 0), (1536, 2048, 3, np.uint8, 1)):
+        rng = np.random.default_rng(0)
+        img = rng.integers(0, 256, size=(4, H, W, Cc) if Cc == 3 else (4, H, W)).astype(dt_np)
+        p = torch.from_numpy(img.view(np.uint8).reshape(4, -1)).to(dev)
+        batch = p[torch.arange(B, device=dev) % 4].contiguous()
+        eng = capi.Engine(device=0, max_h=H, max_w=W, max_c=3, max_batch=B)
+        out = torch.empty(B * H * W * Cc, dtype=torch.float32 if f32 else torch.float64, device=dev)
+        st = capi.current_stream_ptr(dev)
+        code = capi.np_dtype_code(dt_np)
+
+        def step():
+            capi._check(capi.lib.lfa_gaussian_batch(eng._h, batch.data_ptr(), code, B, H, W, Cc, 1.0, None, 0, out.data_ptr(), f32, st))
+        dt = timed(step)
+        byts = B * H * W * Cc * (np.dtype(dt_np).itemsize + (4 if f32 else 8))
+        print(json.dumps({"config": f"gaussian sigma=1 {H}x{W}x{Cc} {np.dtype(dt_np).name} -> {'f32' if f32 else 'f64'}", "images": B,
+                          "ms_per_step": round(dt * 1e3, 3), "GBps_algorithmic": round(byts / dt / 1e9, 1),
+                          "frac_hbm": round(byts / dt / 8e12, 4)}))
+        eng.close()
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["u16", "rois", "gauss"]
+    if "u16" in what: bench_u16()
+    if "rois" in what: bench_rois()
+    if "gauss" in what: bench_gauss()
