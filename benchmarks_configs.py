@@ -102,8 +102,28 @@ def bench_gauss(B=64):
         eng.close()
 
 
+def bench_peaks(n=16384, length=288):
+    rng = np.random.default_rng(0)
+    x = np.arange(length)
+    prof = 180 - 40 * np.exp(-0.5 * ((x - 0.35 * length) / 6) ** 2) - 25 * np.exp(-0.5 * ((x - 0.5 * length) / 6) ** 2)
+    buf = np.round((prof[None, :] + rng.normal(0, 2.0, size=(n, length))) * 60) / 60
+    bt = capi.to_device(buf, dev); lt = capi.to_device(np.full(n, length, np.int32), dev)
+    out = capi.dev_bytes(n * 40, dev)
+    eng = capi.Engine(device=0, max_h=64, max_w=64, max_c=1, max_batch=1)
+    st = capi.current_stream_ptr(dev)
+    for two in (0, 1):
+        def step():
+            capi._check(capi.lib.lfa_peaks_batch(eng._h, bt.data_ptr(), lt.data_ptr(), n, length, 0, 25, two, 15, out.data_ptr(), st))
+        dt = timed(step, 5)
+        pk = capi.from_device(out, capi.PEAKS_DT, n)
+        print(json.dumps({"config": f"k_peaks two={two}", "profiles": n, "length": length, "ms": round(dt * 1e3, 3),
+                          "profiles_per_s": round(n / dt, 1), "mean_peak_width": float((pk["end"][:, 0] - pk["start"][:, 0]).mean())}))
+    eng.close()
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["u16", "rois", "gauss"]
     if "u16" in what: bench_u16()
     if "rois" in what: bench_rois()
     if "gauss" in what: bench_gauss()
+    if "peaks" in what: bench_peaks()

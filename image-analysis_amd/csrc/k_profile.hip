@@ -100,6 +100,45 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
     } else if (dwords) {
         const int64_t b0 = ((int64_t)roi.r0 * j.W + roi.c0) * C * esz;       // first byte of row 0 of the ROI
         const int64_t nbytes = (int64_t)ne * esz;
+        if ((row_bytes & 15) == 0) {
+            // 16-byte chunks (a quarter of the load instructions of the dword form); same item scheme, four in flight per lane
+            const int64_t a0 = b0 & ~(int64_t)15;                              // row_bytes % 16 == 0: same phase on every row
+            const int nch = (int)(((b0 + nbytes + 15) & ~(int64_t)15) - a0) >> 4;
+            const int items = len * nch;
+            const int q64 = 64 / nch, m64 = 64 - q64 * nch;
+            int r = lane / nch, d = lane - r * nch;
+            for (int it0 = lane; it0 < items; it0 += 64 * 4) {
+                uint4 x[4];
+                int rr[4], dd[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    rr[u] = r; dd[u] = d;
+                    if (it0 + 64 * u < items) x[u] = *(const uint4*)(base + (int64_t)r * row_bytes + a0 + 16 * (int64_t)d);
+                    else x[u] = make_uint4(0u, 0u, 0u, 0u);
+                    r += q64; d += m64;
+                    if (d >= nch) { d -= nch; ++r; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (it0 + 64 * u >= items) break;
+                    const unsigned int wds[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+                    unsigned int sv = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int64_t a = a0 + 16 * (int64_t)dd[u] + 4 * k;
+                        unsigned int vm = 0xffffffffu;
+                        if (a + 4 <= b0 || a >= b0 + nbytes) vm = 0u;
+                        else {
+                            if (a < b0) vm &= 0xffffffffu << (8 * (int)(b0 - a));
+                            if (a + 4 > b0 + nbytes) vm &= 0xffffffffu >> (8 * (int)(a + 4 - (b0 + nbytes)));
+                        }
+                        const unsigned int y = wds[k] & vm;
+                        sv = (esz == 1) ? __builtin_amdgcn_sad_u8(y, 0u, sv) : (sv + (y & 0xffffu) + (y >> 16));
+                    }
+                    if (sv) atomicAdd(&rs[rr[u]], sv);
+                }
+            }
+        } else {
         const int64_t a0 = b0 & ~(int64_t)3;                                   // row_bytes % 4 == 0: same phase on every row
         const int ndw = (int)(((b0 + nbytes + 3) & ~(int64_t)3) - a0) >> 2;    // dwords covering one row
         const int items = len * ndw;
@@ -128,6 +167,7 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
                 const unsigned int sv = (esz == 1) ? __builtin_amdgcn_sad_u8(y, 0u, 0u) : ((y & 0xffffu) + (y >> 16));
                 if (sv) atomicAdd(&rs[rr[u]], sv);
             }
+        }
         }
     } else if (work) {
         const int sub = lane & 15, grp = lane >> 4;

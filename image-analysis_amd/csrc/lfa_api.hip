@@ -382,12 +382,14 @@ int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H,
     if (!out) return fail(LFA_ERR_ARG, "null output pointer");
     double w[2 * lfa::kGaussMaxRadius + 1];
     if (host_weights) {
-        if (radius < 0 || radius > lfa::kGaussMaxRadius) return fail(LFA_ERR_UNSUPPORTED, "radius %d outside [0,%d]", radius, lfa::kGaussMaxRadius);
+        if (radius < 1 || radius > lfa::kGaussMaxRadius) return fail(LFA_ERR_UNSUPPORTED, "radius %d outside [1,%d]", radius, lfa::kGaussMaxRadius);
         for (int k = 0; k < 2 * radius + 1; ++k) w[k] = host_weights[k];
+        for (int k = 0; k < radius; ++k)
+            if (w[k] != w[2 * radius - k]) return fail(LFA_ERR_UNSUPPORTED, "kernel taps must be symmetric (scipy's correlate1d symmetric path)");
     } else {
         if (!(sigma > 0.0)) return fail(LFA_ERR_ARG, "sigma must be > 0");
         radius = (int)(4.0 * sigma + 0.5);
-        if (radius > lfa::kGaussMaxRadius) return fail(LFA_ERR_UNSUPPORTED, "sigma %.3f needs radius %d > %d", sigma, radius, lfa::kGaussMaxRadius);
+        if (radius < 1 || radius > lfa::kGaussMaxRadius) return fail(LFA_ERR_UNSUPPORTED, "sigma %.3f needs radius %d outside [1,%d]", sigma, radius, lfa::kGaussMaxRadius);
         // scipy.ndimage._filters._gaussian_kernel1d: exp(-0.5 / sigma^2 * x^2), normalised by the plain sum
         const double sigma2 = sigma * sigma;
         double sum = 0.0;

@@ -198,3 +198,12 @@ def test_gaussian_matches_scipy(det, shape, dtype):
     want = O.gaussian(img, 1.0)
     assert got.dtype == np.float64 and got.shape == want.shape
     np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)     # SURVEY.md section 8a row a16 tolerance
+    assert np.array_equal(got, want)                                  # and in fact bit-exact (same tap order, no FMA)
+
+
+@pytest.mark.parametrize("sigma", [0.5, 1.5, 2.0])
+def test_gaussian_other_sigmas(det, sigma):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, size=(70, 300, 3)).astype(np.uint8)
+    got = det.gaussian(img, sigma=sigma)
+    np.testing.assert_allclose(got, O.gaussian(img, sigma), rtol=1e-12, atol=1e-15)
