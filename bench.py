@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--cpu-sample", type=int, default=48, help="images for the CPU baseline (0 = skip)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (one LfaHandle each) the chunks alternate on")
+    ap.add_argument("--threads", type=int, default=0, help="1: one host thread per stream issues that stream's chunks")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
@@ -103,7 +104,30 @@ def main():
     peaks = capi.dev_bytes(B * max_strips * capi.PEAKS_DT.itemsize, dev)
     import ctypes
 
+    def lane_work(lane, ns):
+        for ci, b0 in enumerate(range(0, B, CH)):
+            if ci % ns != lane:
+                continue
+            nb = min(CH, B - b0)
+            e = engs[lane]
+            stream = ctypes.c_void_p(streams[lane].cuda_stream)
+            capi._check(capi.lib.lfa_analyze_batch(
+                e._h, batch.data_ptr() + b0 * img_bytes, capi.LFA_U8, nb, H, W, C, mm_r, mm_c, 10,
+                strips.data_ptr() + b0 * max_strips * capi.STRIP_DT.itemsize, max_strips,
+                counts.data_ptr() + b0 * 4, info.data_ptr() + b0 * capi.INFO_DT.itemsize,
+                rois.data_ptr() + b0 * max_strips * capi.ROI_DT.itemsize,
+                profiles.data_ptr() + b0 * max_strips * stride * 8, stride,
+                peaks.data_ptr() + b0 * max_strips * capi.PEAKS_DT.itemsize, stream))
+
+    pool_exec = None
+    if args.threads:
+        from concurrent.futures import ThreadPoolExecutor
+        pool_exec = ThreadPoolExecutor(max_workers=NS)
+
     def step(ns=NS):
+        if pool_exec is not None and ns > 1:
+            list(pool_exec.map(lambda l: lane_work(l, ns), range(ns)))
+            return
         for ci, b0 in enumerate(range(0, B, CH)):
             nb = min(CH, B - b0)
             e = engs[ci % ns]

@@ -3,29 +3,29 @@
 // Reference: /root/reference/LFA-Image_Analysis/detection.py:205-245 (image_analysis), :247-281
 // (inverse_image_analysis), :283-316 (analyze_peaks).  profile[k] = np.nanmean(window, axis=cols(+channels))[k]; for the
 // integer images this path handles that is an exact integer row sum and one float64 division.  The peak logic is the
-// shared sequential code of lfa_algo.h (bit-for-bit numpy summation order) run by one wave with a wave-parallel
-// first-extremum search.
+// shared sequential code of lfa_algo.h (bit-for-bit numpy summation order) run by a group of 16 or 64 lanes with a
+// group-parallel first-extremum search.
 #include "lfa_internal.h"
 #include "lfa_algo.h"
 #include "lfa_device.h"
 
 namespace lfa {
 
-constexpr int kProfLds = 4096;     // profiles up to this length are staged in LDS for the peak search
-
-// np.argmax / np.argmin over p[0..n): first extremum, first NaN wins.  Called by all 64 lanes of one wave.
-struct WaveArgExt {
+// np.argmax / np.argmin over p[0..n): first extremum, first NaN wins.  Called by the G lanes of one group (G = 16 or 64
+// consecutive lanes of a wave) with identical arguments; other groups of the wave may run other profiles.
+template <int G>
+struct GroupArgExt {
     __device__ int operator()(const double* p, int n, bool want_min) const {
-        const int lane = threadIdx.x & 63;
+        const int lg = threadIdx.x & (G - 1);
         double m = 0.0; int idx = 0x7fffffff; bool isn = false;
-        for (int i = lane; i < n; i += 64) {
+        for (int i = lg; i < n; i += G) {
             const double x = p[i];
             if (idx == 0x7fffffff) { m = x; idx = i; isn = (x != x); if (isn) break; continue; }
             const bool upd = want_min ? !(x >= m) : !(x <= m);
             if (upd) { m = x; idx = i; if (x != x) { isn = true; break; } }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = G / 2; o > 0; o >>= 1) {
             const double m2 = __shfl_xor(m, o);
             const int i2 = __shfl_xor(idx, o);
             const int n2 = __shfl_xor((int)isn, o);
@@ -54,22 +54,39 @@ __device__ inline void store_peaks(LfaPeaks* dst, const TwoPeaks& t, int length)
     *dst = r;
 }
 
-// One WAVE per ROI, up to four ROIs per block (the peak search is sequential per profile, so the parallelism is across
-// ROIs; the LDS per wave is `lstride` float64 + `lstride` uint32 slots, chosen at launch from the profile stride).
+__device__ inline void store_bad(LfaPeaks* dst, int len) {
+    LfaPeaks r; r.n_peaks = -1; r.length = len; r.start[0] = r.start[1] = r.end[0] = r.end[1] = -1;
+    r.area[0] = r.area[1] = 0.0;
+    *dst = r;
+}
+
+// bytes [b0, b0+nbytes) of a row, dword at byte offset a: sum of the pixels inside (uint8: bytes, uint16: halves)
+__device__ inline unsigned int masked_sum(unsigned int x, int64_t a, int64_t b0, int64_t nbytes, int esz, unsigned int acc) {
+    unsigned int vm = 0xffffffffu;
+    if (a + 4 <= b0 || a >= b0 + nbytes) return acc;
+    if (a < b0) vm &= 0xffffffffu << (8 * (int)(b0 - a));
+    if (a + 4 > b0 + nbytes) vm &= 0xffffffffu >> (8 * (int)(a + 4 - (b0 + nbytes)));
+    const unsigned int y = x & vm;
+    return (esz == 1) ? __builtin_amdgcn_sad_u8(y, 0u, acc) : (acc + (y & 0xffffu) + (y >> 16));
+}
+
+// G lanes per ROI (16: four ROIs per wave; 64: one), blockDim.x / G ROIs per block.  The peak search is sequential per
+// profile, so the parallelism is across ROIs; each ROI has `lstride` float64 slots of LDS.
 //   pooled: lfa_analyze_batch -- k_box_sums already wrote the window's integer row sums, no pixel is read here;
-//   dwords: the ROI's rows are read as aligned dwords, every (row, dword) an independent item, row sums in LDS atomics;
-//   plain:  16 lanes per row (unaligned batches, or profiles longer than the LDS slots: then the peak search reads
-//           the profile from global memory).
+//   wide:   the ROI's rows are read as aligned 16-byte (or 4-byte) pieces, every (row, piece) an independent item with
+//           several loads in flight per lane; integer row sums accumulate in LDS as exact float64 (ds_add_f64);
+//   plain:  lanes stride over a row's elements (unaligned batches, or profiles longer than the LDS slots: then the
+//           peak search reads the profile from global memory).
 // In every mode profile[r] = integer row sum / element count in float64.
+template <int G>
 __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int n_rois, const int32_t* counts, int slots,
                                                  const int32_t* rs_off, int inverse, int rng, double* profiles, int stride,
                                                  LfaPeaks* peaks, int lstride) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int wpb = blockDim.x >> 6;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double* sp = (double*)smem + (int64_t)wv * lstride;
-    unsigned int* rs = (unsigned int*)((double*)smem + (int64_t)wpb * lstride) + (int64_t)wv * lstride;
-    const int ri = blockIdx.x * wpb + wv;
+    const int rpb = blockDim.x / G;                              // ROIs per block
+    const int slot = threadIdx.x / G, lg = threadIdx.x & (G - 1);
+    double* sp = (double*)smem + (int64_t)slot * lstride;
+    const int ri = blockIdx.x * rpb + slot;
     bool valid = ri < n_rois;
     if (valid && counts && (ri % slots) >= counts[ri / slots]) valid = false;   // analyze path: slot beyond this image's strips
     LfaRoi roi; roi.image = 0; roi.r0 = roi.r1 = roi.c0 = roi.c1 = 0;
@@ -87,171 +104,199 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
     const bool use_lds = lstride > 0 && len <= lstride;
     const int64_t row_bytes = (int64_t)j.W * C * esz;
     const int pooled = (work && rs_off && use_lds) ? rs_off[ri] : -1;
-    // u8 row sums fit 32 bits for any supported width; u16 rows up to 65536 elements too
-    const bool dwords = work && pooled < 0 && use_lds && j.aligned16 && (row_bytes & 3) == 0 && ne > 0 && (esz == 1 || ne <= 65536);
-    if (dwords) for (int r = lane; r < len; r += 64) rs[r] = 0;
+    const bool wide = work && pooled < 0 && use_lds && j.aligned16 && (row_bytes & 3) == 0 && ne > 0;
+    if (wide) for (int r = lg; r < len; r += G) sp[r] = 0.0;
     __syncthreads();
     if (pooled >= 0) {
         const uint32_t* rsum = j.rowsum + (int64_t)roi.image * j.rowsum_cap + pooled;
-        for (int r = lane; r < len; r += 64) {
-            const double m = (double)rsum[r] / cnt;
-            prof[r] = m; sp[r] = m;
+        for (int r = lg; r < len; r += G) {
+            prof[r] = (double)rsum[r] / cnt;
         }
-    } else if (dwords) {
+    } else if (wide) {
         const int64_t b0 = ((int64_t)roi.r0 * j.W + roi.c0) * C * esz;       // first byte of row 0 of the ROI
         const int64_t nbytes = (int64_t)ne * esz;
         if ((row_bytes & 15) == 0) {
-            // 16-byte chunks (a quarter of the load instructions of the dword form); same item scheme, four in flight per lane
             const int64_t a0 = b0 & ~(int64_t)15;                              // row_bytes % 16 == 0: same phase on every row
             const int nch = (int)(((b0 + nbytes + 15) & ~(int64_t)15) - a0) >> 4;
             const int items = len * nch;
-            const int q64 = 64 / nch, m64 = 64 - q64 * nch;
-            int r = lane / nch, d = lane - r * nch;
-            for (int it0 = lane; it0 < items; it0 += 64 * 4) {
+            const int qg = G / nch, mg = G - qg * nch;                         // (row, piece) advance by G items without a division
+            int r = lg / nch, d = lg - r * nch;
+            for (int it0 = lg; it0 < items; it0 += G * 4) {
                 uint4 x[4];
                 int rr[4], dd[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     rr[u] = r; dd[u] = d;
-                    if (it0 + 64 * u < items) x[u] = *(const uint4*)(base + (int64_t)r * row_bytes + a0 + 16 * (int64_t)d);
+                    if (it0 + G * u < items) x[u] = *(const uint4*)(base + (int64_t)r * row_bytes + a0 + 16 * (int64_t)d);
                     else x[u] = make_uint4(0u, 0u, 0u, 0u);
-                    r += q64; d += m64;
+                    r += qg; d += mg;
                     if (d >= nch) { d -= nch; ++r; }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (it0 + 64 * u >= items) break;
-                    const unsigned int wds[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
-                    unsigned int sv = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int64_t a = a0 + 16 * (int64_t)dd[u] + 4 * k;
-                        unsigned int vm = 0xffffffffu;
-                        if (a + 4 <= b0 || a >= b0 + nbytes) vm = 0u;
-                        else {
-                            if (a < b0) vm &= 0xffffffffu << (8 * (int)(b0 - a));
-                            if (a + 4 > b0 + nbytes) vm &= 0xffffffffu >> (8 * (int)(a + 4 - (b0 + nbytes)));
-                        }
-                        const unsigned int y = wds[k] & vm;
-                        sv = (esz == 1) ? __builtin_amdgcn_sad_u8(y, 0u, sv) : (sv + (y & 0xffffu) + (y >> 16));
-                    }
-                    if (sv) atomicAdd(&rs[rr[u]], sv);
+                    if (it0 + G * u >= items) break;
+                    const int64_t a = a0 + 16 * (int64_t)dd[u];
+                    unsigned int sv = masked_sum(x[u].x, a, b0, nbytes, esz, 0u);
+                    sv = masked_sum(x[u].y, a + 4, b0, nbytes, esz, sv);
+                    sv = masked_sum(x[u].z, a + 8, b0, nbytes, esz, sv);
+                    sv = masked_sum(x[u].w, a + 12, b0, nbytes, esz, sv);
+                    if (sv) unsafeAtomicAdd(&sp[rr[u]], (double)sv);
                 }
             }
         } else {
-        const int64_t a0 = b0 & ~(int64_t)3;                                   // row_bytes % 4 == 0: same phase on every row
-        const int ndw = (int)(((b0 + nbytes + 3) & ~(int64_t)3) - a0) >> 2;    // dwords covering one row
-        const int items = len * ndw;
-        // eight independent loads per lane are issued before any of them is used (the loop is latency-bound otherwise);
-        // (row, dword) of item `it` advance by 64 items per step without a division
-        const int q64 = 64 / ndw, m64 = 64 - q64 * ndw;
-        int r = lane / ndw, d = lane - r * ndw;
-        for (int it0 = lane; it0 < items; it0 += 64 * 8) {
-            unsigned int x[8];
-            int rr[8], dd[8];
+            const int64_t a0 = b0 & ~(int64_t)3;                               // row_bytes % 4 == 0: same phase on every row
+            const int ndw = (int)(((b0 + nbytes + 3) & ~(int64_t)3) - a0) >> 2;
+            const int items = len * ndw;
+            const int qg = G / ndw, mg = G - qg * ndw;
+            int r = lg / ndw, d = lg - r * ndw;
+            for (int it0 = lg; it0 < items; it0 += G * 8) {
+                unsigned int x[8];
+                int rr[8], dd[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                rr[u] = r; dd[u] = d;
-                x[u] = (it0 + 64 * u < items) ? *(const unsigned int*)(base + (int64_t)r * row_bytes + a0 + 4 * (int64_t)d) : 0u;
-                r += q64; d += m64;
-                if (d >= ndw) { d -= ndw; ++r; }
-            }
+                for (int u = 0; u < 8; ++u) {
+                    rr[u] = r; dd[u] = d;
+                    x[u] = (it0 + G * u < items) ? *(const unsigned int*)(base + (int64_t)r * row_bytes + a0 + 4 * (int64_t)d) : 0u;
+                    r += qg; d += mg;
+                    if (d >= ndw) { d -= ndw; ++r; }
+                }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (it0 + 64 * u >= items) break;
-                const int64_t a = a0 + 4 * (int64_t)dd[u];
-                unsigned int vm = 0xffffffffu;
-                if (a < b0) vm &= 0xffffffffu << (8 * (int)(b0 - a));
-                if (a + 4 > b0 + nbytes) vm &= 0xffffffffu >> (8 * (int)(a + 4 - (b0 + nbytes)));
-                const unsigned int y = x[u] & vm;
-                const unsigned int sv = (esz == 1) ? __builtin_amdgcn_sad_u8(y, 0u, 0u) : ((y & 0xffffu) + (y >> 16));
-                if (sv) atomicAdd(&rs[rr[u]], sv);
+                for (int u = 0; u < 8; ++u) {
+                    if (it0 + G * u >= items) break;
+                    const unsigned int sv = masked_sum(x[u], a0 + 4 * (int64_t)dd[u], b0, nbytes, esz, 0u);
+                    if (sv) unsafeAtomicAdd(&sp[rr[u]], (double)sv);
+                }
             }
-        }
         }
     } else if (work) {
-        const int sub = lane & 15, grp = lane >> 4;
-        for (int r = grp; r < len + 3; r += 4) {            // all 16 lanes of a group stay together for the shuffles
-            const bool in = r < len;
-            const int64_t e0 = ((int64_t)(roi.r0 + (in ? r : 0)) * j.W + roi.c0) * C;
-            unsigned long long s = 0;
-            if (in) {
-                if (esz == 1) { for (int k = sub; k < ne; k += 16) s += base[e0 + k]; }
-                else { const uint16_t* b16 = (const uint16_t*)base; for (int k = sub; k < ne; k += 16) s += b16[e0 + k]; }
-            }
-            s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-            if (in && sub == 0) {
-                const double m = (double)s / cnt;         // ne == 0 -> 0/0 = NaN, like np.nanmean of an empty slice
+        for (int r = 0; r < len; ++r) {                     // G lanes share a row
+            const int64_t e0 = ((int64_t)(roi.r0 + r) * j.W + roi.c0) * C;
+            unsigned long long sm = 0;
+            if (esz == 1) { for (int k = lg; k < ne; k += G) sm += base[e0 + k]; }
+            else { const uint16_t* b16 = (const uint16_t*)base; for (int k = lg; k < ne; k += G) sm += b16[e0 + k]; }
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+            if (lg == 0) {
+                const double m = (double)sm / cnt;        // ne == 0 -> 0/0 = NaN, like np.nanmean of an empty slice
                 prof[r] = m;
-                if (use_lds) sp[r] = m;
             }
         }
     }
     __syncthreads();
-    if (dwords)
-        for (int r = lane; r < len; r += 64) {
-            const double m = (double)rs[r] / cnt;
-            prof[r] = m; sp[r] = m;
+    if (wide)
+        for (int r = lg; r < len; r += G) {
+            prof[r] = sp[r] / cnt;
         }
-    __syncthreads();
-    if (bad) {
-        if (lane == 0) { LfaPeaks r; r.n_peaks = -1; r.length = len; r.start[0] = r.start[1] = r.end[0] = r.end[1] = -1;
-                         r.area[0] = r.area[1] = 0.0; peaks[ri] = r; }
-        return;
-    }
-    if (!work) return;
-    const double* p = use_lds ? sp : prof;
-    const TwoPeaks tp = two_peaks_t(p, len, inverse != 0, rng, inverse == 0, 25, WaveArgExt());
-    if (lane == 0) store_peaks(&peaks[ri], tp, len);
+    if (bad && lg == 0) store_bad(&peaks[ri], len);               // k_peaks skips ROIs it finds bad by the same test
 }
 
-// analyze_peaks / the two-peak logic on caller-supplied profiles: one wave per profile
-__global__ __launch_bounds__(64) void k_peaks(const double* profiles, const int32_t* lengths, int n, int stride,
-                                              int inverse, int window, int two, int rng, LfaPeaks* out) {
-    __shared__ double sp[kProfLds];
-    const int i = blockIdx.x;
-    if (i >= n) return;
-    const int len = lengths[i];
-    const double* g = profiles + (int64_t)i * stride;
-    const bool bad = len < 0 || len > stride;
-    if (bad) { if (threadIdx.x == 0) { LfaPeaks r; r.n_peaks = -1; r.length = len; r.start[0] = r.start[1] = r.end[0] = r.end[1] = -1;
-                                        r.area[0] = r.area[1] = 0.0; out[i] = r; } return; }
-    const bool use_lds = len <= kProfLds;
-    if (use_lds) for (int k = threadIdx.x; k < len; k += 64) sp[k] = g[k];
+// analyze_peaks / the two-peak logic on profiles in global memory: G lanes per profile, profiles staged in LDS.
+// Lengths come from `lengths` (lfa_peaks_batch) or from the ROI list the profiles were computed for (rois != null).
+template <int G>
+__global__ __launch_bounds__(256) void k_peaks(const double* profiles, const int32_t* lengths, int n, int stride,
+                                               int inverse, int window, int two, int rng, LfaPeaks* out, int lstride,
+                                               Job j, const LfaRoi* rois, const int32_t* counts, int slots) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int ppb = blockDim.x / G;
+    const int slot = threadIdx.x / G, lg = threadIdx.x & (G - 1);
+    double* sp = (double*)smem + (int64_t)slot * lstride;
+    const int i = blockIdx.x * ppb + slot;
+    bool valid = i < n;
+    int len = 0;
+    bool bad = false;
+    if (valid && rois) {
+        if (counts && (i % slots) >= counts[i / slots]) valid = false;
+        if (valid) {
+            const LfaRoi roi = rois[i];
+            len = roi.r1 - roi.r0;
+            bad = roi.image < 0 || roi.image >= j.n || roi.r0 < 0 || roi.r1 > j.H || roi.c0 < 0 || roi.c1 > j.W ||
+                  len < 0 || roi.c1 < roi.c0 || len > stride;
+        }
+    } else if (valid) {
+        len = lengths[i];
+        bad = len < 0 || len > stride;
+    }
+    const double* g = profiles + (int64_t)(valid ? i : 0) * stride;
+    const bool work = valid && !bad;
+    const bool use_lds = lstride > 0 && len <= lstride;
+    if (work && use_lds) for (int k = lg; k < len; k += G) sp[k] = g[k];
     __syncthreads();
+    if (bad) { if (lg == 0) store_bad(&out[i], len); return; }
+    if (!work) return;
     const double* p = use_lds ? sp : g;
     TwoPeaks tp;
     if (two) {
-        tp = two_peaks_t(p, len, inverse != 0, rng, inverse == 0, window, WaveArgExt());
+        tp = two_peaks_t(p, len, inverse != 0, rng, inverse == 0, window, GroupArgExt<G>());
     } else {
         tp.n = 0;
         if (len > 0) {
-            const int pk = WaveArgExt()(p, len, inverse != 0);
+            const int pk = GroupArgExt<G>()(p, len, inverse != 0);
             tp.n = 1; tp.pk[0] = analyze_peaks_at(p, len, pk, inverse != 0, window); tp.pk[1] = tp.pk[0];
         }
     }
-    if (threadIdx.x == 0) store_peaks(&out[i], tp, len);
+    if (lg == 0) store_peaks(&out[i], tp, len);
+}
+
+// LDS plan: `lstride` float64 slots per profile.  Prefer 16 lanes per profile (4 per wave) with as many waves per block as
+// 64 KiB allow; fall back to one wave per profile, then to no LDS staging at all.
+struct LdsPlan { int g, threads, lstride; size_t bytes; };
+
+static LdsPlan plan_lds(int max_len) {
+    LdsPlan p;
+    const int ls = (max_len + 1) & ~1;
+    const size_t per = (size_t)ls * 8;
+    if (per * 4 <= 65536) {                         // one wave of four 16-lane groups fits
+        int waves = 4;
+        while (waves > 1 && per * 4 * waves > 65536) waves >>= 1;
+        p.g = 16; p.threads = 64 * waves; p.lstride = ls; p.bytes = per * 4 * waves;
+    } else if (per <= 65536) {
+        p.g = 64; p.threads = 64; p.lstride = ls; p.bytes = per;
+    } else {
+        p.g = 64; p.threads = 256; p.lstride = 0; p.bytes = 0;
+    }
+    return p;
+}
+
+static void launch_peaks_k(const double* profiles, const int32_t* lengths, int n, int stride, int max_len, int inverse,
+                           int window, int two, int rng, LfaPeaks* out, const Job& j, const LfaRoi* rois,
+                           const int32_t* counts, int slots, hipStream_t s) {
+    const LdsPlan p = plan_lds(max_len);
+    const int ppb = p.threads / p.g;
+    const dim3 grid((n + ppb - 1) / ppb), block(p.threads);
+    if (p.g == 16)
+        LFA_LAUNCH("k_peaks", k_peaks<16>, grid, block, p.bytes, s, profiles, lengths, n, stride, inverse, window, two, rng, out,
+                   p.lstride, j, rois, counts, slots);
+    else
+        LFA_LAUNCH("k_peaks", k_peaks<64>, grid, block, p.bytes, s, profiles, lengths, n, stride, inverse, window, two, rng, out,
+                   p.lstride, j, rois, counts, slots);
 }
 
 hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const int32_t* counts, int slots,
                            const int32_t* rs_off, int inverse, int rng, double* profiles, int stride, LfaPeaks* peaks,
                            hipStream_t s) {
     if (n_rois <= 0) return hipSuccess;
-    // LDS per wave: 12 bytes per profile slot; up to 4 waves per block within 64 KiB; no LDS staging beyond that
-    int lstride = (stride + 1) & ~1;
-    int wpb = 4;
-    while (wpb > 1 && (size_t)wpb * lstride * 12 > 65536) wpb >>= 1;
-    if ((size_t)wpb * lstride * 12 > 65536) lstride = 0;
-    const size_t lds = (size_t)wpb * lstride * 12;
-    LFA_LAUNCH("k_profile", k_profile, dim3((n_rois + wpb - 1) / wpb), dim3(64 * wpb), lds, s, j, rois, n_rois, counts, slots,
-               rs_off, inverse, rng, profiles, stride, peaks, lstride);
+    // the analyze path only ever profiles windows of int(.6h) - int(.25h) <= 0.35*H + 1 rows: size the LDS for that
+    int max_len = stride;
+    if (counts) { const int wl = (int)(0.35 * j.H) + 2; if (wl < max_len) max_len = wl; }
+    // row sums: one wave per ROI (all 64 lanes keep loads in flight), float64 accumulators in LDS
+    {
+        const int ls = (max_len + 1) & ~1;
+        int waves = 4;
+        while (waves > 1 && (size_t)waves * ls * 8 > 65536) waves >>= 1;
+        const int lstride = ((size_t)waves * ls * 8 <= 65536) ? ls : 0;
+        if (!lstride) waves = 4;
+        LFA_LAUNCH("k_profile", k_profile<64>, dim3((n_rois + waves - 1) / waves), dim3(64 * waves), (size_t)waves * lstride * 8, s,
+                   j, rois, n_rois, counts, slots, rs_off, inverse, rng, profiles, stride, peaks, lstride);
+    }
+    // peaks: the sequential search, 16 lanes per profile
+    launch_peaks_k(profiles, nullptr, n_rois, stride, max_len, inverse, 25, 1, rng, peaks, j, rois, counts, slots, s);
     return hipGetLastError();
 }
 
 hipError_t launch_peaks(const double* profiles, const int32_t* lengths, int n, int stride, int inverse, int window,
                         int two, int rng, LfaPeaks* out, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    LFA_LAUNCH("k_peaks", k_peaks, dim3(n), dim3(64), 0, s, profiles, lengths, n, stride, inverse, window, two, rng, out);
+    Job j{};
+    launch_peaks_k(profiles, lengths, n, stride, stride, inverse, window, two, rng, out, j, nullptr, nullptr, 0, s);
     return hipGetLastError();
 }
 
