@@ -1,0 +1,73 @@
+// mall_probe.hip -- measurement tool, not part of the library.
+// How fast can a streaming read go when the same bytes are read again shortly afterwards (Infinity Cache reuse)?
+//   1. one buffer of S bytes read 20 times in a row, S from 32 MiB to 4 GiB;
+//   2. a 2.25 GiB buffer cut into groups of S bytes, every group read 3 times back to back (the min/max, histogram and
+//      mask passes of the LFA front end) before the next group is touched.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/mall_probe.hip -o tools/mall_probe
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void k_read(const uint4* p, size_t n16, unsigned int* sink) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    unsigned int acc = 0;
+    for (; i + 3 * step < n16; i += 4 * step) {
+        const uint4 a = p[i], b = p[i + step], c = p[i + 2 * step], d = p[i + 3 * step];
+        acc += a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+    }
+    for (; i < n16; i += step) { const uint4 a = p[i]; acc += a.x ^ a.y ^ a.z ^ a.w; }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+static int grid_for(size_t n16) {
+    size_t blocks = (n16 + 256 * 8 - 1) / (256 * 8);      // about 8 x 16 bytes per lane
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int main() {
+    const size_t total = (size_t)2304 << 20;
+    const size_t big = (size_t)4096 << 20;
+    uint8_t* buf; unsigned int* sink;
+    CK(hipMalloc(&buf, big)); CK(hipMalloc(&sink, 4));
+    CK(hipMemset(buf, 1, big));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipStream_t s; CK(hipStreamCreate(&s));
+    printf("test,bytes_MiB,ms,GBps\n");
+    const size_t sizes[] = {32, 64, 96, 128, 160, 192, 224, 256, 320, 384, 512, 1024, 2304, 4096};
+    for (size_t si = 0; si < sizeof(sizes) / sizeof(sizes[0]); ++si) {
+        const size_t S = sizes[si] << 20, n16 = S / 16;
+        const int g = grid_for(n16);
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k_read, dim3(g), dim3(256), 0, s, (const uint4*)buf, n16, sink);
+        CK(hipEventRecord(e0, s));
+        const int reps = 20;
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_read, dim3(g), dim3(256), 0, s, (const uint4*)buf, n16, sink);
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("repeat,%zu,%.4f,%.1f\n", sizes[si], ms / reps, (double)S * reps / (ms * 1e6));
+    }
+    const size_t groups[] = {16, 32, 64, 96, 128, 160, 192, 256, 576, 2304};
+    for (size_t gi = 0; gi < sizeof(groups) / sizeof(groups[0]); ++gi) {
+        const size_t S = groups[gi] << 20, n16 = S / 16;
+        const int g = grid_for(n16);
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0, s));
+            for (size_t off = 0; off + S <= total; off += S)
+                for (int pass = 0; pass < 3; ++pass)
+                    hipLaunchKernelGGL(k_read, dim3(g), dim3(256), 0, s, (const uint4*)(buf + off), n16, sink);
+            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        const size_t covered = (total / S) * S;
+        printf("3pass_groups,%zu,%.4f,%.1f\n", groups[gi], best, (double)covered * 3 / (best * 1e6));
+    }
+    CK(hipGetLastError());
+    return 0;
+}
