@@ -58,6 +58,7 @@ def _load():
     lib.lfa_set_debug_flags.restype = i32
     lib.lfa_detect_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     lib.lfa_profile_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp]
+    lib.lfa_profile_lut_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, vp]
     lib.lfa_peaks_batch.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.lfa_analyze_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.lfa_gaussian_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, dbl, vp, i32, vp, i32, vp]
@@ -66,8 +67,8 @@ def _load():
     lib.lfa_timing_enable.argtypes = [vp, C.c_char_p]
     lib.lfa_timing_read.argtypes = [vp, i32, vp, vp, vp, vp]
     for name in ("lfa_timing_enable", "lfa_timing_read","lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant", "lfa_detect_batch",
-                 "lfa_profile_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch", "lfa_debug_fetch",
-                 "lfa_sync"):
+                 "lfa_profile_batch", "lfa_profile_lut_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch",
+                 "lfa_debug_fetch", "lfa_sync"):
         getattr(lib, name).restype = i32
     return lib
 
@@ -76,8 +77,8 @@ lib = _load()
 
 EXPORTED = ("lfa_version", "lfa_last_error", "lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant",
             "lfa_set_debug_flags",
-            "lfa_detect_batch", "lfa_profile_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch",
-            "lfa_debug_fetch", "lfa_sync", "lfa_timing_enable", "lfa_timing_read")
+            "lfa_detect_batch", "lfa_profile_batch", "lfa_profile_lut_batch", "lfa_peaks_batch", "lfa_analyze_batch",
+            "lfa_gaussian_batch", "lfa_debug_fetch", "lfa_sync", "lfa_timing_enable", "lfa_timing_read")
 
 
 def _check(rc):
@@ -96,6 +97,36 @@ def numpy_gamma_lut_u16(gamma=0.4):
     """adjust_gamma on every uint16 value (exposure.py:674-679), built with this host's numpy."""
     x = np.arange(65536, dtype=np.uint16)
     return (((x / 65535.0) ** gamma) * 65535.0 * 1).astype(np.uint16)
+
+
+def point_op_lut(dtype, gamma_level=1, low_exposure=None, high_exposure=None, invert=False):
+    """Table of MyGUI.analyze_plot's point operations (detection.py:535-539) over every value of `dtype` (uint8/uint16):
+    adjust_gamma (exposure.py:666-681), rescale_intensity(in_range=(low, high)) when either bound is set
+    (exposure.py:577-600, out_range='dtype'), util.invert (util/_invert.py:64-66).  Computed with this host's numpy on
+    arange(all values), so table[v] has exactly the bits the reference produces for a pixel v."""
+    dt = np.dtype(dtype)
+    if dt == np.uint8:
+        if gamma_level < 0:
+            raise ValueError("Gamma should be a non-negative real number.")
+        v = numpy_gamma_lut_u8(gamma_level)                      # adjust_gamma on uint8 IS this table (lut[image])
+    elif dt == np.uint16:
+        if gamma_level < 0:
+            raise ValueError("Gamma should be a non-negative real number.")
+        v = numpy_gamma_lut_u16(gamma_level)
+    else:
+        raise TypeError("point-operation tables exist for uint8 and uint16 pixels only")
+    top = float(np.iinfo(dt).max)
+    if low_exposure is not None or high_exposure is not None:
+        imin, imax = map(float, (low_exposure, high_exposure))   # a single None raises TypeError, like the reference (:582)
+        w = np.clip(v, imin, imax)
+        if imin != imax:
+            w = (w - imin) / (imax - imin)
+            v = np.asarray(w * (top - 0.0) + 0.0, dtype=dt)
+        else:
+            v = np.clip(w, 0.0, top).astype(dt)
+    if invert:
+        v = np.subtract(np.iinfo(dt).max, v, dtype=dt)
+    return np.ascontiguousarray(v, dtype=dt)
 
 
 def detect_gray_variant():
@@ -250,13 +281,21 @@ class Engine:
                                      profiles.data_ptr(), stride, peaks.data_ptr(), current_stream_ptr(self.device)))
         return strips, counts, info, rois, profiles, peaks
 
-    def profile_raw(self, images_t, dtype_code, n, H, W, Cc, rois_t, n_rois, inverse, rng, stride):
+    def profile_raw(self, images_t, dtype_code, n, H, W, Cc, rois_t, n_rois, inverse, rng, stride, luts_t=None, n_luts=0,
+                    roi_lut_t=None):
         torch = _torch()
         profiles = torch.empty(max(n_rois, 1) * stride, dtype=torch.float64, device=self.device)
         peaks = dev_bytes(max(n_rois, 1) * PEAKS_DT.itemsize, self.device)
-        _check(lib.lfa_profile_batch(self._h, images_t.data_ptr(), dtype_code, n, H, W, Cc, rois_t.data_ptr(), n_rois,
-                                     int(bool(inverse)), int(rng), profiles.data_ptr(), stride, peaks.data_ptr(),
-                                     current_stream_ptr(self.device)))
+        if luts_t is None:
+            _check(lib.lfa_profile_batch(self._h, images_t.data_ptr(), dtype_code, n, H, W, Cc, rois_t.data_ptr(), n_rois,
+                                         int(bool(inverse)), int(rng), profiles.data_ptr(), stride, peaks.data_ptr(),
+                                         current_stream_ptr(self.device)))
+        else:
+            _check(lib.lfa_profile_lut_batch(self._h, images_t.data_ptr(), dtype_code, n, H, W, Cc, rois_t.data_ptr(), n_rois,
+                                             luts_t.data_ptr(), int(n_luts),
+                                             roi_lut_t.data_ptr() if roi_lut_t is not None else None,
+                                             int(bool(inverse)), int(rng), profiles.data_ptr(), stride, peaks.data_ptr(),
+                                             current_stream_ptr(self.device)))
         return profiles, peaks
 
     # -- numpy-level helpers -----------------------------------------------------------------------------------------
@@ -320,8 +359,11 @@ class Engine:
             infos.append(inf.copy())
         return res, np.concatenate(infos)
 
-    def profiles(self, images: np.ndarray, rois: np.ndarray, inverse=False, rng=15):
-        """Row-mean profiles + peaks of arbitrary ROIs (ROI_DT array) over a batch resident in one upload."""
+    def profiles(self, images: np.ndarray, rois: np.ndarray, inverse=False, rng=15, luts=None, roi_lut=None):
+        """Row-mean profiles + peaks of arbitrary ROIs (ROI_DT array) over a batch resident in one upload.
+
+        luts: optional (n_luts, 256) uint8 / (n_luts, 65536) uint16 point-operation tables (`point_op_lut`), applied to
+        every pixel before the row mean; roi_lut: table index per ROI (default: table 0)."""
         images, n, H, W, Cc, code = self._prep(images)
         if n > self.max_batch:
             raise ValueError("batch larger than the engine's max_batch")
@@ -332,7 +374,21 @@ class Engine:
         stride = max(1, int((rois["r1"] - rois["r0"]).max()))
         t = to_device(images, self.device)
         rt = to_device(rois, self.device)
-        profiles, peaks = self.profile_raw(t, code, n, H, W, Cc, rt, n_rois, inverse, rng, stride)
+        lt = rlt = None
+        n_luts = 0
+        if luts is not None:
+            luts = np.ascontiguousarray(luts)
+            entries = 256 if images.dtype == np.uint8 else 65536
+            if luts.dtype != images.dtype or luts.ndim not in (1, 2) or luts.shape[-1] != entries:
+                raise ValueError(f"luts must be {images.dtype} tables of {entries} entries")
+            n_luts = 1 if luts.ndim == 1 else luts.shape[0]
+            lt = to_device(luts, self.device)
+            if roi_lut is not None:
+                roi_lut = np.ascontiguousarray(roi_lut, dtype=np.int32)
+                if roi_lut.shape != (n_rois,):
+                    raise ValueError("roi_lut needs one table index per ROI")
+                rlt = to_device(roi_lut, self.device)
+        profiles, peaks = self.profile_raw(t, code, n, H, W, Cc, rt, n_rois, inverse, rng, stride, lt, n_luts, rlt)
         pk = from_device(peaks, PEAKS_DT, n_rois)
         pr = profiles.cpu().numpy().reshape(n_rois, stride)
         return [pr[i, :max(0, pk[i]["length"])].copy() for i in range(n_rois)], pk.copy()

@@ -70,6 +70,27 @@ __device__ inline unsigned int masked_sum(unsigned int x, int64_t a, int64_t b0,
     return (esz == 1) ? __builtin_amdgcn_sad_u8(y, 0u, acc) : (acc + (y & 0xffffu) + (y >> 16));
 }
 
+// same with a point-operation table applied to every pixel first (lfa_profile_lut_batch): l8 = 256 bytes in LDS, l16 =
+// 65536 halves in global memory
+__device__ inline unsigned int masked_lut_sum(unsigned int x, int64_t a, int64_t b0, int64_t nbytes, int esz, unsigned int acc,
+                                              const uint8_t* l8, const uint16_t* l16) {
+    if (a + 4 <= b0 || a >= b0 + nbytes) return acc;
+    if (esz == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t pos = a + k;
+            if (pos >= b0 && pos < b0 + nbytes) acc += l8[(x >> (8 * k)) & 0xffu];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int64_t pos = a + 2 * k;
+            if (pos >= b0 && pos < b0 + nbytes) acc += l16[(x >> (16 * k)) & 0xffffu];
+        }
+    }
+    return acc;
+}
+
 // G lanes per ROI (16: four ROIs per wave; 64: one), blockDim.x / G ROIs per block.  The peak search is sequential per
 // profile, so the parallelism is across ROIs; each ROI has `lstride` float64 slots of LDS.
 //   pooled: lfa_analyze_batch -- k_box_sums already wrote the window's integer row sums, no pixel is read here;
@@ -78,10 +99,13 @@ __device__ inline unsigned int masked_sum(unsigned int x, int64_t a, int64_t b0,
 //   plain:  lanes stride over a row's elements (unaligned batches, or profiles longer than the LDS slots: then the
 //           peak search reads the profile from global memory).
 // In every mode profile[r] = integer row sum / element count in float64.
-template <int G>
+// LUT: every pixel goes through a point-operation table first (luts: n_luts tables of 256 u8 / 65536 u16; roi_lut: table
+// index per ROI or null = table 0); the uint8 table of a ROI is copied to LDS behind the accumulators.
+template <int G, bool LUT>
 __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int n_rois, const int32_t* counts, int slots,
                                                  const int32_t* rs_off, int inverse, int rng, double* profiles, int stride,
-                                                 LfaPeaks* peaks, int lstride) {
+                                                 LfaPeaks* peaks, int lstride, const uint8_t* luts, const int32_t* roi_lut,
+                                                 int n_luts) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int rpb = blockDim.x / G;                              // ROIs per block
     const int slot = threadIdx.x / G, lg = threadIdx.x & (G - 1);
@@ -92,8 +116,13 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
     LfaRoi roi; roi.image = 0; roi.r0 = roi.r1 = roi.c0 = roi.c1 = 0;
     if (valid) roi = rois[ri];
     const int len = roi.r1 - roi.r0;
+    const int li = (LUT && valid && roi_lut) ? roi_lut[ri] : 0;
     const bool bad = valid && (roi.image < 0 || roi.image >= j.n || roi.r0 < 0 || roi.r1 > j.H || roi.c0 < 0 || roi.c1 > j.W ||
-                               len < 0 || roi.c1 < roi.c0 || len > stride);
+                               len < 0 || roi.c1 < roi.c0 || len > stride || li < 0 || (LUT && li >= n_luts));
+    uint8_t* l8 = smem + (int64_t)rpb * lstride * 8 + slot * 256;             // LUT, uint8 images only
+    const uint16_t* l16 = (const uint16_t*)luts + (int64_t)(bad ? 0 : li) * 65536;
+    if (LUT && j.dtype != LFA_U16 && valid && !bad)
+        for (int k = lg; k < 256; k += G) l8[k] = luts[(int64_t)li * 256 + k];
     const bool work = valid && !bad;
     double* prof = profiles + (int64_t)(valid ? ri : 0) * stride;
     const uint8_t* base = j.images + (int64_t)(work ? roi.image : 0) * j.img_bytes;
@@ -136,10 +165,18 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
                 for (int u = 0; u < 4; ++u) {
                     if (it0 + G * u >= items) break;
                     const int64_t a = a0 + 16 * (int64_t)dd[u];
-                    unsigned int sv = masked_sum(x[u].x, a, b0, nbytes, esz, 0u);
-                    sv = masked_sum(x[u].y, a + 4, b0, nbytes, esz, sv);
-                    sv = masked_sum(x[u].z, a + 8, b0, nbytes, esz, sv);
-                    sv = masked_sum(x[u].w, a + 12, b0, nbytes, esz, sv);
+                    unsigned int sv;
+                    if (LUT) {
+                        sv = masked_lut_sum(x[u].x, a, b0, nbytes, esz, 0u, l8, l16);
+                        sv = masked_lut_sum(x[u].y, a + 4, b0, nbytes, esz, sv, l8, l16);
+                        sv = masked_lut_sum(x[u].z, a + 8, b0, nbytes, esz, sv, l8, l16);
+                        sv = masked_lut_sum(x[u].w, a + 12, b0, nbytes, esz, sv, l8, l16);
+                    } else {
+                        sv = masked_sum(x[u].x, a, b0, nbytes, esz, 0u);
+                        sv = masked_sum(x[u].y, a + 4, b0, nbytes, esz, sv);
+                        sv = masked_sum(x[u].z, a + 8, b0, nbytes, esz, sv);
+                        sv = masked_sum(x[u].w, a + 12, b0, nbytes, esz, sv);
+                    }
                     if (sv) unsafeAtomicAdd(&sp[rr[u]], (double)sv);
                 }
             }
@@ -162,7 +199,8 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     if (it0 + G * u >= items) break;
-                    const unsigned int sv = masked_sum(x[u], a0 + 4 * (int64_t)dd[u], b0, nbytes, esz, 0u);
+                    const unsigned int sv = LUT ? masked_lut_sum(x[u], a0 + 4 * (int64_t)dd[u], b0, nbytes, esz, 0u, l8, l16)
+                                                : masked_sum(x[u], a0 + 4 * (int64_t)dd[u], b0, nbytes, esz, 0u);
                     if (sv) unsafeAtomicAdd(&sp[rr[u]], (double)sv);
                 }
             }
@@ -171,8 +209,8 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
         for (int r = 0; r < len; ++r) {                     // G lanes share a row
             const int64_t e0 = ((int64_t)(roi.r0 + r) * j.W + roi.c0) * C;
             unsigned long long sm = 0;
-            if (esz == 1) { for (int k = lg; k < ne; k += G) sm += base[e0 + k]; }
-            else { const uint16_t* b16 = (const uint16_t*)base; for (int k = lg; k < ne; k += G) sm += b16[e0 + k]; }
+            if (esz == 1) { for (int k = lg; k < ne; k += G) sm += LUT ? l8[base[e0 + k]] : base[e0 + k]; }
+            else { const uint16_t* b16 = (const uint16_t*)base; for (int k = lg; k < ne; k += G) sm += LUT ? l16[b16[e0 + k]] : b16[e0 + k]; }
 #pragma unroll
             for (int o = G / 2; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
             if (lg == 0) {
@@ -194,7 +232,8 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
 template <int G>
 __global__ __launch_bounds__(256) void k_peaks(const double* profiles, const int32_t* lengths, int n, int stride,
                                                int inverse, int window, int two, int rng, LfaPeaks* out, int lstride,
-                                               Job j, const LfaRoi* rois, const int32_t* counts, int slots) {
+                                               Job j, const LfaRoi* rois, const int32_t* counts, int slots,
+                                               const int32_t* roi_lut, int n_luts) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ppb = blockDim.x / G;
     const int slot = threadIdx.x / G, lg = threadIdx.x & (G - 1);
@@ -210,6 +249,7 @@ __global__ __launch_bounds__(256) void k_peaks(const double* profiles, const int
             len = roi.r1 - roi.r0;
             bad = roi.image < 0 || roi.image >= j.n || roi.r0 < 0 || roi.r1 > j.H || roi.c0 < 0 || roi.c1 > j.W ||
                   len < 0 || roi.c1 < roi.c0 || len > stride;
+            if (roi_lut && (roi_lut[i] < 0 || roi_lut[i] >= n_luts)) bad = true;
         }
     } else if (valid) {
         len = lengths[i];
@@ -258,21 +298,21 @@ static LdsPlan plan_lds(int max_len) {
 
 static void launch_peaks_k(const double* profiles, const int32_t* lengths, int n, int stride, int max_len, int inverse,
                            int window, int two, int rng, LfaPeaks* out, const Job& j, const LfaRoi* rois,
-                           const int32_t* counts, int slots, hipStream_t s) {
+                           const int32_t* counts, int slots, const int32_t* roi_lut, int n_luts, hipStream_t s) {
     const LdsPlan p = plan_lds(max_len);
     const int ppb = p.threads / p.g;
     const dim3 grid((n + ppb - 1) / ppb), block(p.threads);
     if (p.g == 16)
         LFA_LAUNCH("k_peaks", k_peaks<16>, grid, block, p.bytes, s, profiles, lengths, n, stride, inverse, window, two, rng, out,
-                   p.lstride, j, rois, counts, slots);
+                   p.lstride, j, rois, counts, slots, roi_lut, n_luts);
     else
         LFA_LAUNCH("k_peaks", k_peaks<64>, grid, block, p.bytes, s, profiles, lengths, n, stride, inverse, window, two, rng, out,
-                   p.lstride, j, rois, counts, slots);
+                   p.lstride, j, rois, counts, slots, roi_lut, n_luts);
 }
 
 hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const int32_t* counts, int slots,
                            const int32_t* rs_off, int inverse, int rng, double* profiles, int stride, LfaPeaks* peaks,
-                           hipStream_t s) {
+                           const uint8_t* luts, int n_luts, const int32_t* roi_lut, hipStream_t s) {
     if (n_rois <= 0) return hipSuccess;
     // the analyze path only ever profiles windows of int(.6h) - int(.25h) <= 0.35*H + 1 rows: size the LDS for that
     int max_len = stride;
@@ -284,11 +324,18 @@ hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const i
         while (waves > 1 && (size_t)waves * ls * 8 > 65536) waves >>= 1;
         const int lstride = ((size_t)waves * ls * 8 <= 65536) ? ls : 0;
         if (!lstride) waves = 4;
-        LFA_LAUNCH("k_profile", k_profile<64>, dim3((n_rois + waves - 1) / waves), dim3(64 * waves), (size_t)waves * lstride * 8, s,
-                   j, rois, n_rois, counts, slots, rs_off, inverse, rng, profiles, stride, peaks, lstride);
+        const dim3 grid((n_rois + waves - 1) / waves), block(64 * waves);
+        const size_t acc_bytes = (size_t)waves * lstride * 8;
+        if (luts)
+            LFA_LAUNCH("k_profile_lut", (k_profile<64, true>), grid, block, acc_bytes + (size_t)waves * 256, s, j, rois, n_rois, counts,
+                       slots, rs_off, inverse, rng, profiles, stride, peaks, lstride, luts, roi_lut, n_luts);
+        else
+            LFA_LAUNCH("k_profile", (k_profile<64, false>), grid, block, acc_bytes, s, j, rois, n_rois, counts, slots, rs_off,
+                       inverse, rng, profiles, stride, peaks, lstride, luts, roi_lut, n_luts);
     }
     // peaks: the sequential search, 16 lanes per profile
-    launch_peaks_k(profiles, nullptr, n_rois, stride, max_len, inverse, 25, 1, rng, peaks, j, rois, counts, slots, s);
+    launch_peaks_k(profiles, nullptr, n_rois, stride, max_len, inverse, 25, 1, rng, peaks, j, rois, counts, slots,
+                   luts ? roi_lut : nullptr, n_luts, s);
     return hipGetLastError();
 }
 
@@ -296,7 +343,7 @@ hipError_t launch_peaks(const double* profiles, const int32_t* lengths, int n, i
                         int two, int rng, LfaPeaks* out, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     Job j{};
-    launch_peaks_k(profiles, lengths, n, stride, stride, inverse, window, two, rng, out, j, nullptr, nullptr, 0, s);
+    launch_peaks_k(profiles, lengths, n, stride, stride, inverse, window, two, rng, out, j, nullptr, nullptr, 0, nullptr, 0, s);
     return hipGetLastError();
 }
 

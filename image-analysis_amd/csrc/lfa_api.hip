@@ -316,12 +316,13 @@ int lfa_detect_batch(LfaHandle h, const void* images, int dtype, int n, int H, i
                        out_info, nullptr, (hipStream_t)stream, nullptr);
 }
 
-int lfa_profile_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, const LfaRoi* rois,
-                      int n_rois, int inverse, int range, double* out_profiles, int profile_stride, LfaPeaks* out_peaks,
-                      void* stream) {
+static int profile_impl(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, const LfaRoi* rois,
+                        int n_rois, const void* luts, int n_luts, const int32_t* roi_lut, bool with_lut, int inverse, int range,
+                        double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream) {
     int rc = check_images(h, images, dtype, n, H, W, C);
     if (rc) return rc;
     if (n_rois < 0) return fail(LFA_ERR_ARG, "n_rois < 0");
+    if (with_lut && (!luts || n_luts < 1)) return fail(LFA_ERR_ARG, "luts must hold at least one table");
     if (n_rois == 0) return LFA_OK;
     if (!rois || !out_profiles || !out_peaks) return fail(LFA_ERR_ARG, "null pointer");
     if (profile_stride < 1) return fail(LFA_ERR_ARG, "profile_stride must be >= 1");
@@ -333,8 +334,23 @@ int lfa_profile_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
     j.aligned16 = (((uintptr_t)images & 15) == 0 && (j.img_bytes & 15) == 0) ? 1 : 0;
     TimerScope ts(h);
     LFA_HIP(lfa::launch_profiles(j, rois, n_rois, nullptr, 0, nullptr, inverse, range, out_profiles, profile_stride, out_peaks,
+                                 with_lut ? (const uint8_t*)luts : nullptr, n_luts, with_lut ? roi_lut : nullptr,
                                  (hipStream_t)stream));
     return LFA_OK;
+}
+
+int lfa_profile_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, const LfaRoi* rois,
+                      int n_rois, int inverse, int range, double* out_profiles, int profile_stride, LfaPeaks* out_peaks,
+                      void* stream) {
+    return profile_impl(h, images, dtype, n, H, W, C, rois, n_rois, nullptr, 0, nullptr, false, inverse, range, out_profiles,
+                        profile_stride, out_peaks, stream);
+}
+
+int lfa_profile_lut_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, const LfaRoi* rois,
+                          int n_rois, const void* luts, int n_luts, const int32_t* roi_lut, int inverse, int range,
+                          double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream) {
+    return profile_impl(h, images, dtype, n, H, W, C, rois, n_rois, luts, n_luts, roi_lut, true, inverse, range, out_profiles,
+                        profile_stride, out_peaks, stream);
 }
 
 int lfa_peaks_batch(LfaHandle h, const double* profiles, const int32_t* lengths, int n_profiles, int profile_stride,
@@ -371,7 +387,7 @@ int lfa_analyze_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
     if (rc) return rc;
     TimerScope ts(h);
     LFA_HIP(lfa::launch_profiles(j, out_rois, n * max_strips, out_counts, max_strips, j.slot_rs_off, 0, 15, out_profiles, profile_stride,
-                                 out_peaks, (hipStream_t)stream));
+                                 out_peaks, nullptr, 0, nullptr, (hipStream_t)stream));
     return LFA_OK;
 }
 

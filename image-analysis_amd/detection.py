@@ -125,7 +125,7 @@ def _peaks_to_list(pk):
     return out
 
 
-def _analysis(region, selected, rng, inverse):
+def _analysis(region, selected, rng, inverse, lut=None):
     region = np.asanyarray(region)
     _check_pixels(region)
     flat, c = _as_2d_elements(region)
@@ -143,7 +143,7 @@ def _analysis(region, selected, rng, inverse):
     roi = np.zeros(1, dtype=_capi.ROI_DT)
     roi["image"], roi["r0"], roi["r1"], roi["c0"], roi["c1"] = 0, r0, r1, c0 * c, c1 * c
     eng = _engine(h, we)
-    profiles, peaks = eng.profiles(flat[None], roi, inverse=inverse, rng=int(rng))
+    profiles, peaks = eng.profiles(flat[None], roi, inverse=inverse, rng=int(rng), luts=lut)
     return [profiles[0], _peaks_to_list(peaks[0])]
 
 
@@ -158,6 +158,24 @@ def inverse_image_analysis(region, selected, range=1):
     if region.ndim != 3:
         raise ValueError(f"not enough values to unpack (expected 3, got {region.ndim})")
     return _analysis(region, selected, range, inverse=True)
+
+
+def analyze_plot(region, selected, gamma_level=1, low_exposure=None, high_exposure=None, invert=False):
+    """The data path of MyGUI.analyze_plot (detection.py:535-543): adjust_gamma(region, gamma_level), then
+    rescale_intensity(region, in_range=(low_exposure, high_exposure)) when either is set, then either
+    inverse_image_analysis(util.invert(region), selected) or image_analysis(region, selected).
+
+    The three point operations become one table (`_capi.point_op_lut`, built with the host's numpy) that the profile
+    kernel applies to every pixel it reads; the pre-processed region is never materialised."""
+    region = np.asanyarray(region)
+    if region.dtype not in (np.uint8, np.uint16):
+        raise NotImplementedError("analyze_plot pre-processing is built for uint8 and uint16 regions")
+    lut = _capi.point_op_lut(region.dtype, gamma_level, low_exposure, high_exposure, bool(invert))
+    if invert:
+        if region.ndim != 3:
+            raise ValueError(f"not enough values to unpack (expected 3, got {region.ndim})")
+        return _analysis(region, selected, 1, inverse=True, lut=lut)
+    return _analysis(region, selected, 15, inverse=False, lut=lut)
 
 
 def analyze_peaks(profile, inverse=False, window_size=25):

@@ -151,6 +151,19 @@ int lfa_profile_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
                       const LfaRoi* rois, int n_rois, int inverse, int range,
                       double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream);
 
+/* The same after the per-region point operations MyGUI.analyze_plot applies first (detection.py:535-539):
+ *   region = adjust_gamma(region, gamma_level); rescale_intensity(region, in_range=(low, high)); util.invert(region)
+ * (skimage/exposure/exposure.py:620-681, :485-600; skimage/util/_invert.py:62-74).  On uint8 / uint16 pixels each of them,
+ * and any chain of them, is a value -> value map of the same dtype, i.e. a table; the caller builds the table with the
+ * host's numpy (bit-exact by construction) and every pixel of a ROI goes through it before the row mean.
+ * luts: device, n_luts tables of 256 uint8 (LFA_U8) or 65536 uint16 (LFA_U16) entries, back to back.
+ * roi_lut: device int32[n_rois], the table of each ROI, or NULL = table 0 for all; an index outside [0, n_luts) is
+ * reported through out_peaks[j].n_peaks = -1 like any other bad ROI. */
+int lfa_profile_lut_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C,
+                          const LfaRoi* rois, int n_rois, const void* luts, int n_luts, const int32_t* roi_lut,
+                          int inverse, int range, double* out_profiles, int profile_stride, LfaPeaks* out_peaks,
+                          void* stream);
+
 /* analyze_peaks(profile, inverse, window_size) on caller-supplied float64 profiles (detection.py:283-316).
  * profiles: device, n_profiles * profile_stride float64; lengths: device int32[n_profiles].
  * out: device LfaPeaks[n_profiles] with n_peaks = 1 (start[0], end[0], area[0]); when `two_peaks` != 0 the full

@@ -309,6 +309,44 @@ def inverse_image_analysis(region: np.ndarray, selected: bool, range: int = 1):
 
 
 # --------------------------------------------------------------------------------------------------
+# analyze_plot pre-processing  (detection.py:535-543)
+# --------------------------------------------------------------------------------------------------
+def rescale_intensity(image: np.ndarray, in_range) -> np.ndarray:
+    """skimage.exposure.rescale_intensity(image, in_range=(lo, hi)) with out_range='dtype' (exposure.py:577-600)
+    for the unsigned integer images of this path: the result has the input's dtype."""
+    image = np.asarray(image)
+    if image.dtype.kind != "u":
+        raise NotImplementedError("oracle restates rescale_intensity for unsigned integer images only")
+    imin, imax = map(float, in_range)                                  # :582 (None -> TypeError, like the reference)
+    omin, omax = 0.0, float(np.iinfo(image.dtype).max)                  # :583 intensity_range(image, 'dtype')
+    out = np.clip(image, imin, imax)                                   # :594 (float64: Python-float bounds)
+    if imin != imax:
+        out = (out - imin) / (imax - imin)                             # :597
+        return np.asarray(out * (omax - omin) + omin, dtype=image.dtype)   # :598
+    return np.clip(out, omin, omax).astype(image.dtype)                # :600
+
+
+def invert(image: np.ndarray) -> np.ndarray:
+    """skimage.util.invert for unsigned integers (util/_invert.py:64-66): dtype max - image."""
+    image = np.asarray(image)
+    if image.dtype.kind != "u":
+        raise NotImplementedError("oracle restates invert for unsigned integer images only")
+    return np.subtract(np.iinfo(image.dtype).max, image, dtype=image.dtype)
+
+
+def analyze_plot(region: np.ndarray, selected: bool, gamma_level: float = 1, low_exposure=None, high_exposure=None,
+                 invert_image: bool = False):
+    """MyGUI.analyze_plot's data path (detection.py:535-543): gamma, optional rescale, optional invert, then
+    image_analysis / inverse_image_analysis."""
+    region = adjust_gamma(np.asarray(region), gamma_level)
+    if low_exposure is not None or high_exposure is not None:
+        region = rescale_intensity(region, (low_exposure, high_exposure))
+    if invert_image:
+        return inverse_image_analysis(invert(region), selected)
+    return image_analysis(region, selected)
+
+
+# --------------------------------------------------------------------------------------------------
 # gaussian  (_shared/filters.py:35-166 ; only caller detection.py:166)
 # --------------------------------------------------------------------------------------------------
 def gaussian(image: np.ndarray, sigma: float = 1.0) -> np.ndarray:

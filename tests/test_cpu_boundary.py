@@ -63,6 +63,28 @@ def test_host_tables(capi):
     assert 0 <= v < capi.GRAY_NVARIANTS
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_point_operation_tables_equal_the_oracle_chain(capi, dtype):
+    """point_op_lut(v) == invert(rescale_intensity(adjust_gamma(v))) of the oracle for every pixel value."""
+    from oracle import lfa_oracle as O
+    top = int(np.iinfo(dtype).max)
+    x = np.arange(top + 1, dtype=dtype)
+    cases = [(1, None, None, False), (0.4, None, None, False), (2.2, None, None, True), (1, 10, top // 2, False),
+             (0.75, 3.5, top * 0.9, True), (1, 40, 40, False), (1.3, top, 0, False), (0, 5, 100, True)]
+    for gamma, lo, hi, inv in cases:
+        want = O.adjust_gamma(x, gamma)
+        if lo is not None or hi is not None:
+            want = O.rescale_intensity(want, (lo, hi))
+        if inv:
+            want = O.invert(want)
+        got = capi.point_op_lut(dtype, gamma, lo, hi, inv)
+        assert got.dtype == np.dtype(dtype) and np.array_equal(got, want), (gamma, lo, hi, inv)
+    with pytest.raises(TypeError):
+        capi.point_op_lut(dtype, 1, None, 7)
+    with pytest.raises(ValueError):
+        capi.point_op_lut(dtype, -1)
+
+
 def test_dropin_list_logic_matches_reference_vectors(golden_dir):
     import image_analysis_amd.detection as det
     g = np.load(os.path.join(golden_dir, "ref_region_lists.npz"))

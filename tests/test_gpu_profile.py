@@ -207,3 +207,86 @@ def test_gaussian_other_sigmas(det, sigma):
     img = rng.integers(0, 256, size=(70, 300, 3)).astype(np.uint8)
     got = det.gaussian(img, sigma=sigma)
     np.testing.assert_allclose(got, O.gaussian(img, sigma), rtol=1e-12, atol=1e-15)
+
+
+# ---- analyze_plot pre-processing as a per-ROI table (detection.py:535-543) --------------------
+def _same_analysis(got, want):
+    assert np.array_equal(got[0], want[0])
+    assert len(got[1]) == len(want[1])
+    for (s, e, a), (ws, we, wa) in zip(got[1], want[1]):
+        assert (s, e) == (ws, we) and a == wa
+
+
+@pytest.mark.parametrize("gamma,lo,hi,inv", [(1, None, None, False), (0.45, None, None, False), (1.8, 20, 180, False),
+                                             (1, None, None, True), (0.7, 30, 220, True), (1, 90, 90, False)])
+@pytest.mark.parametrize("selected", [False, True])
+def test_analyze_plot_colour_region(det, gamma, lo, hi, inv, selected):
+    from image_analysis_amd.synth import synth_rgb
+    img = synth_rgb(700, 480, 4, 77)
+    region = img[40:640, 100:163]                               # a strip-sized view (non-contiguous, odd width)
+    got = det.analyze_plot(region, selected, gamma, lo, hi, inv)
+    want = O.analyze_plot(region, selected, gamma, lo, hi, inv)
+    _same_analysis(got, want)
+
+
+@pytest.mark.parametrize("gamma,lo,hi", [(1, None, None), (0.5, None, None), (1.5, 100, 3000), (1, 0, 4095.5)])
+def test_analyze_plot_uint16_region(det, golden_dir, gamma, lo, hi):
+    crop = np.array(Image.open(os.path.join(golden_dir, "excel2_crop.png")))
+    assert crop.dtype == np.uint16
+    for selected in (False, True):
+        _same_analysis(det.analyze_plot(crop, selected, gamma, lo, hi, False), O.analyze_plot(crop, selected, gamma, lo, hi, False))
+    # the GUI's default settings are the identity: same answer as image_analysis (and the excel2 known answer)
+    if gamma == 1 and lo is None:
+        _same_analysis(det.analyze_plot(crop, False), det.image_analysis(crop, False))
+
+
+def test_analyze_plot_errors(det):
+    reg = np.zeros((60, 30), np.uint8)
+    with pytest.raises(ValueError):
+        det.analyze_plot(reg, False, gamma_level=-0.5)
+    with pytest.raises(TypeError):
+        det.analyze_plot(reg, False, 1, None, 100)               # float(None), exposure.py:582
+    with pytest.raises(ValueError):
+        det.analyze_plot(reg, False, invert=True)                # inverse_image_analysis needs 3-D (detection.py:249)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_profile_tables_per_roi_batch(dtype):
+    """Many ROIs, several tables, one call; uint8 widths that are not multiples of 4 take the pixel path."""
+    import image_analysis_amd._capi as capi
+    from image_analysis_amd.synth import synth_rgb, synth_u16, synth_rois
+    if dtype == np.uint8:
+        imgs = np.stack([synth_rgb(640, 258, 3, 9 + i)[:, :, 1] for i in range(2)])          # 2-D uint8, W*C % 4 != 0
+        imgs3 = np.stack([synth_rgb(640, 256, 3, 19 + i) for i in range(2)])
+    else:
+        imgs = np.stack([synth_u16(640, 256, 6, 9 + i) for i in range(2)])
+        imgs3 = None
+    params = [(1, None, None, False), (0.4, None, None, False), (2.0, 5, 200 if dtype == np.uint8 else 3000, True)]
+    luts = np.stack([capi.point_op_lut(dtype, *p) for p in params])
+    for batch in (imgs, imgs3):
+        if batch is None:
+            continue
+        n, H, W = batch.shape[:3]
+        rois = synth_rois(n, H, W, per_image=30, seed=3).astype(capi.ROI_DT)
+        which = (np.arange(len(rois)) % len(params)).astype(np.int32)
+        eng = capi.Engine(device=0, max_h=H, max_w=W, max_batch=n)
+        profs, pk = eng.profiles(batch, rois, inverse=False, rng=15, luts=luts, roi_lut=which)
+        for j, r in enumerate(rois):
+            reg = batch[r["image"], r["r0"]:r["r1"], r["c0"]:r["c1"]]
+            g, lo, hi, inv = params[which[j]]
+            reg = O.adjust_gamma(reg, g)
+            if lo is not None:
+                reg = O.rescale_intensity(reg, (lo, hi))
+            if inv:
+                reg = O.invert(reg)
+            wp, wk = O.image_analysis(reg, True)
+            assert np.array_equal(profs[j], wp), j
+            assert pk[j]["n_peaks"] == len(wk), j
+            for i, (s, e, a) in enumerate(wk):
+                assert (pk[j]["start"][i], pk[j]["end"][i]) == (s, e) and pk[j]["area"][i] == a, j
+        # a table index out of range marks that ROI, and only that ROI, as bad
+        which_bad = which.copy()
+        which_bad[1] = len(params)
+        _p, pk2 = eng.profiles(batch, rois, luts=luts, roi_lut=which_bad)
+        assert pk2[1]["n_peaks"] == -1 and pk2[0]["n_peaks"] == pk[0]["n_peaks"] and pk2[2]["area"][0] == pk[2]["area"][0]
+        eng.close()

@@ -135,3 +135,19 @@ def test_label_order_is_raster_order_of_first_pixel():
         firsts = [np.flatnonzero(lab.ravel() == i)[0] for i in range(1, k + 1)]
         assert firsts == sorted(firsts)
         assert lab.dtype == np.int32
+
+
+def test_point_operations_match_the_reference_docstrings():
+    """rescale_intensity / invert restatements against the examples the reference's vendored skimage holds
+    (skimage/exposure/exposure.py:532-534, skimage/util/_invert.py:43-49); beyond those two vectors the analyze_plot
+    pre-processing is pinned on numpy semantics only ("parity unpinned" in the strict sense)."""
+    img = np.array([51, 102, 153], dtype=np.uint8)
+    assert O.rescale_intensity(img, (51, 153)).tolist() == [0, 127, 255]           # in_range='image' of the example
+    assert O.rescale_intensity(img, (51, 153)).dtype == np.uint8
+    inv = O.invert(np.array([[100, 0, 200], [0, 50, 0], [30, 0, 255]], np.uint8))
+    assert inv.tolist() == [[155, 255, 55], [255, 205, 255], [225, 255, 0]]
+    assert O.invert(np.array([0, 65535, 100], np.uint16)).tolist() == [65535, 0, 65435]
+    # constant in_range: clip to the dtype range (exposure.py:600)
+    assert O.rescale_intensity(img, (100, 100)).tolist() == [100, 100, 100]
+    with pytest.raises(TypeError):
+        O.rescale_intensity(img, (None, 100))
