@@ -32,6 +32,50 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
         const uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
         G_thr = eg[kEdgesI_MaskThr];
         integer_path = eg[kEdgesI_MaskCrit] == 0;
+        if (VEC && j.bins && eg[kEdgesI_Bins]) {
+            // the bin plane k_hist_rgb wrote decides every pixel outside the threshold's own bin: 1 byte per pixel
+            // instead of 3; a pixel IN that bin is settled by the exact compare on the image itself
+            const int ncg = W >> 4;
+            const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+            if (item >= (int64_t)j.HB * ncg) return;
+            const int rb = (int)(item / ncg), cg = (int)(item % ncg);
+            const int r0 = rb * 64;
+            const int rows = min(64, H - r0);
+            const uint32_t best = (uint32_t)inf.otsu_bin;
+            const uint32_t best4 = best * 0x01010101u;
+            const uint8_t* bp = j.bins + (int64_t)img * H * W + (int64_t)r0 * W + (int64_t)cg * 16;
+            uint32_t lo[16], hi[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { lo[k] = 0; hi[k] = 0; }
+            auto brow = [&](int r, uint32_t (&acc)[16], uint32_t rbit) {
+                const uint4 a = *(const uint4*)(bp + (int64_t)r * W);
+                const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] |= (byte_of(w, k) > best) ? rbit : 0u;
+                uint32_t anyeq = 0;                                  // a zero byte in w ^ best4 <=> some pixel is in bin `best`
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const uint32_t v = w[q] ^ best4; anyeq |= (v - 0x01010101u) & ~v & 0x80808080u; }
+                if (anyeq) {
+                    const uint8_t* q = base + ((int64_t)(r0 + r) * W + (int64_t)cg * 16) * 3;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        if (byte_of(w, k) == best && (2125u * q[3 * k] + 7154u * q[3 * k + 1] + 721u * q[3 * k + 2]) >= G_thr) acc[k] |= rbit;
+                }
+            };
+            const int rows_lo = min(rows, 32);
+#pragma unroll 4
+            for (int r = 0; r < rows_lo; ++r) brow(r, lo, 1u << r);
+#pragma unroll 4
+            for (int r = 32; r < rows; ++r) brow(r, hi, 1u << (r - 32));
+            uint64_t* o = out + (int64_t)rb * W + cg * 16;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                uint4 v;
+                v.x = lo[k]; v.y = hi[k]; v.z = lo[k + 1]; v.w = hi[k + 1];
+                *(uint4*)(o + k) = v;
+            }
+            return;
+        }
     }
 
     if (VEC) {

@@ -319,14 +319,16 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
         }
         __syncthreads();
     }
-    auto addG = [&](uint32_t G) {                          // integer path: see g_threshold
+    auto addG = [&](uint32_t G) -> uint32_t {              // integer path: see g_threshold
         int k = tab[G >> 10];                               // bin of the bucket start: a lower bound
         const uint32_t e1 = sg[k + 1], e2 = sg[k + 2];      // one LDS access for the two next edges
         k += (G >= e1) ? 1 : 0;
         k += (G >= e2) ? 1 : 0;
         if (G >= e2) { while (G >= sg[k + 1]) ++k; }        // dark pixels: bins narrower than a bucket (sg[256..] = inf ends it)
         atomicAdd(&sh[k * kCopies + cp], 1u);
+        return (uint32_t)k;
     };
+    uint8_t* bins = j.bins ? j.bins + (int64_t)img * npix : nullptr;   // bin plane for k_mask (integer path only)
     auto add = [&](double g) {                             // float64 path (an edge is critical): exact compares + census
         const float vf = __builtin_amdgcn_exp2f(0.4f * __builtin_amdgcn_logf((float)g));
         int k = (int)((vf - vminf) * scalef);
@@ -346,12 +348,17 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
             for (int64_t g = tid; g < ng; g += nth) {
                 uint32_t w[12];
                 load48(base + g * 48, w);
+                uint32_t pk[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int k = 0; k < 16; ++k) addG(gray_G16(w, k));
+                for (int k = 0; k < 16; ++k) pk[k >> 2] |= addG(gray_G16(w, k)) << (8 * (k & 3));
+                if (bins) *(uint4*)(bins + g * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
             done = ng << 4;
         }
-        for (int64_t p = done + tid; p < npix; p += nth) addG(gray_G(base[3 * p], base[3 * p + 1], base[3 * p + 2]));
+        for (int64_t p = done + tid; p < npix; p += nth) {
+            const uint32_t k = addG(gray_G(base[3 * p], base[3 * p + 1], base[3 * p + 2]));
+            if (bins) bins[p] = (uint8_t)k;
+        }
     } else {
         if (j.aligned16) {
             const int64_t ng = npix >> 4;
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
         if (t == 0) {
             inf->v_thr_f = inf->vmin; inf->g_thr = __longlong_as_double(0x7ff0000000000000LL);
             uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
-            eg[kEdgesI_MaskThr] = kGInf; eg[kEdgesI_MaskCrit] = 0u;
+            eg[kEdgesI_MaskThr] = kGInf; eg[kEdgesI_MaskCrit] = 0u; eg[kEdgesI_Bins] = 0u;
         }
         return;
     }
@@ -518,8 +525,14 @@ __global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
     // integer form of `gray >= T` for k_mask (critical -> k_mask takes the float64 path)
     uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
     bool crit = false;
-    eg[kEdgesI_MaskThr] = g_threshold(T, &crit);
+    const uint32_t G_thr = g_threshold(T, &crit);
+    eg[kEdgesI_MaskThr] = G_thr;
     eg[kEdgesI_MaskCrit] = (crit || (j.debug_flags & 1)) ? 1u : 0u;
+    // k_mask may decide from the bin plane alone (bin > best: set, bin < best: clear, bin == best: exact compare) iff the
+    // histogram took the integer path (the plane was written), the threshold has an exact integer form and sits inside
+    // its own bin in integer terms: E[best] <= G_thr <= E[best+1]  (E[256] = +inf)
+    const uint32_t e_lo = eg[best], e_hi = (best + 1 <= 255) ? eg[best + 1] : kGInf;
+    eg[kEdgesI_Bins] = (j.bins && eg[kEdgesI_Crit] == 0 && !crit && !(j.debug_flags & 1) && e_lo <= G_thr && G_thr <= e_hi) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -78,13 +78,13 @@ struct LfaContext {
     int max_h = 0, max_w = 0, max_c = 0, max_batch = 0;
     int gray_variant = LFA_GRAY_FMA_102;
     int debug_flags = 0;
-    Buf info, hist, edges, edges_i, maskT, col_cnt, run_se, run_col, parent, area, bbox, firstbits, wordrank, root_of_label, cand,
+    Buf info, hist, edges, edges_i, bins, maskT, col_cnt, run_se, run_col, parent, area, bbox, firstbits, wordrank, root_of_label, cand,
         cand_sum, cand_rs_off, rowsum, slot_rs_off, lut8, lut16, rois;
     lfa::Job last{};
     bool have_last = false;
     EventTimer* timer = nullptr;
     std::vector<Buf*> all() {
-        return {&info, &hist, &edges, &edges_i, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &firstbits, &wordrank,
+        return {&info, &hist, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &firstbits, &wordrank,
                 &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &lut8, &lut16, &rois};
     }
 };
@@ -115,7 +115,7 @@ int run_capacity(int H, int W, int L) {
 }
 
 // size every buffer for (n images of H x W, line_length L, dtype); grows only
-int ensure_workspace(LfaContext* h, int n, int H, int W, int dtype, int L, int max_strips) {
+int ensure_workspace(LfaContext* h, int n, int H, int W, int C, int dtype, int L, int max_strips) {
     const size_t N = (size_t)n;
     const int HB = (H + 63) / 64, W64 = (W + 63) / 64;
     const size_t cap = (size_t)run_capacity(H, W, L);
@@ -125,6 +125,7 @@ int ensure_workspace(LfaContext* h, int n, int H, int W, int dtype, int L, int m
     if ((rc = ensure(h->hist, N * hist_stride * 4))) return rc;
     if ((rc = ensure(h->edges, N * lfa::kEdges * 8))) return rc;
     if ((rc = ensure(h->edges_i, N * lfa::kEdgesI * 4))) return rc;
+    if (C == 3 && (rc = ensure(h->bins, N * (size_t)H * W))) return rc;
     if ((rc = ensure(h->maskT, N * HB * W * 8))) return rc;
     if ((rc = ensure(h->col_cnt, N * (W + 1) * 4))) return rc;
     if ((rc = ensure(h->run_se, N * cap * 4))) return rc;
@@ -176,6 +177,8 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.hist_stride = (dtype == LFA_U16) ? lfa::kHistBinsU16 : 256;
     j.edges_g = (double*)h->edges.p;
     j.edges_i = (uint32_t*)h->edges_i.p;
+    // bin plane: colour images on the vector paths only (16-pixel groups in k_hist_rgb, 16-column groups in k_mask)
+    j.bins = (C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2)) ? (uint8_t*)h->bins.p : nullptr;
     j.maskT = (uint64_t*)h->maskT.p;
     j.col_cnt = (uint32_t*)h->col_cnt.p;
     j.run_se = (uint32_t*)h->run_se.p;
@@ -213,7 +216,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (!out_strips || !out_counts) return fail(LFA_ERR_ARG, "null output pointer");
     if (max_strips < 1 || max_strips > 1024) return fail(LFA_ERR_ARG, "max_strips must be in [1,1024]");
     LFA_HIP(hipSetDevice(h->device));
-    if ((rc = ensure_workspace(h, n, H, W, dtype, L, max_strips))) return rc;
+    if ((rc = ensure_workspace(h, n, H, W, C, dtype, L, max_strips))) return rc;
     lfa::Job j = make_job(h, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
     lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
     TimerScope ts(h);
@@ -263,7 +266,7 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         lfa_destroy(h);
         return fail(LFA_ERR_HIP, "uploading gamma tables failed");
     }
-    if ((rc = ensure_workspace(h, max_batch, max_h, max_w, LFA_U16, 10, 64))) { lfa_destroy(h); return rc; }
+    if ((rc = ensure_workspace(h, max_batch, max_h, max_w, max_c, LFA_U16, 10, 64))) { lfa_destroy(h); return rc; }
     *out = h;
     return LFA_OK;
 }

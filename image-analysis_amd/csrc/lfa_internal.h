@@ -15,6 +15,7 @@ constexpr int kEdgesI = 264;             // integer edge record per image: 257 t
 constexpr int kEdgesI_Crit = 257;        // != 0: some histogram edge is critical -> float64 histogram path
 constexpr int kEdgesI_MaskThr = 258;     // integer form of the mask threshold
 constexpr int kEdgesI_MaskCrit = 259;    // != 0: mask threshold critical -> float64 mask path
+constexpr int kEdgesI_Bins = 260;        // != 0: the image's bin plane (Job::bins) is valid and k_mask may use it
 constexpr int kAreaMin = 100;            // detection.py:81
 constexpr int kMaxCand = 1 << 20;
 
@@ -41,6 +42,8 @@ struct Job {
     int32_t hist_stride;
     double* edges_g;         // [n][257]  gray-space bin edges (colour path)
     uint32_t* edges_i;       // [n][264]  the same as integer thresholds on G = 2125*b0 + 7154*b1 + 721*b2 (k_threshold.hip)
+    uint8_t* bins;           // [n][H*W]  colour path: histogram bin of every pixel, written by k_hist_rgb and read by k_mask
+                             //           instead of the image (1 byte per pixel instead of 3); null = not used
     uint64_t* maskT;         // [n][HB][W]      vertical 64-row words, thresholded image
     uint32_t* col_cnt;       // [n][W+1]        runs per column -> exclusive offsets
     uint32_t* run_se;        // [n][run_cap]    start | (end_inclusive << 16)
