@@ -101,6 +101,35 @@ def test_colour_float64_fallback_path(capi, eng, seed):
         eng.set_debug_flags(0)
 
 
+def test_colour_bin_plane_paths_agree(capi, eng):
+    """k_mask decides from the bin plane k_hist_rgb wrote (bin > Otsu bin: set, <: clear, ==: exact compare on the image).
+    Images with few distinct gray levels put many pixels INTO the threshold's bin; both that path and the plane-less path
+    (debug flag 2) must reproduce the oracle, and `otsu_bin` must be populated."""
+    rng = np.random.default_rng(2024)
+    cases = []
+    base = rng.integers(50, 61, size=(192, 256), dtype=np.uint8)                 # 11 levels: one value per occupied bin
+    img = np.stack([base, base, base], axis=2)
+    img[20:170, 40:52] = 58
+    img[20:170, 100:112] = 60
+    cases.append(img)
+    two = np.full((192, 256, 3), 90, np.uint8)                                   # two levels + a sprinkle of a third
+    two[10:180, 60:75] = 91
+    two[10:180, 140:150] = (91, 90, 92)
+    two[rng.random((192, 256)) < 0.01] = 89
+    cases.append(two)
+    wide = rng.integers(0, 256, size=(192, 256, 3), dtype=np.uint8)              # every bin populated, channels independent
+    wide[30:160, 80:96] = (250, 251, 249)
+    cases.append(wide)
+    for img in cases:
+        for flags in (0, 2):
+            eng.set_debug_flags(flags)
+            try:
+                d = check_detect(capi, eng, img, 60, 10)
+            finally:
+                eng.set_debug_flags(0)
+        assert d["mask"].any() and not d["mask"].all()
+
+
 def test_colour_extreme_values(capi, eng):
     """black and saturated pixels, all 256 levels per channel, strongly different channels"""
     rng = np.random.default_rng(77)
