@@ -280,11 +280,17 @@ __global__ void k_zero_hist_u16(Job j) {
 
 template <int V>
 __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
-    __shared__ uint32_t sh[256 * kCopies];
+    // 32 sub-histograms, one per LDS bank: lane l only ever touches bank l & 31, so the atomics of a wave never collide on
+    // a bank whatever the bins are.  Two 16-bit counters per dword (bins 2q, 2q+1) keep that at 16 KiB; a counter is
+    // fed by the 8 lanes of the block that share l & 31, so it stays below 2^16 while a block handles <= 2^21 pixels
+    // (launch_threshold sizes the grid accordingly).
+    __shared__ uint32_t sh[128 * 32];
     __shared__ double st[kEdges + 1];
     const int img = blockIdx.y;
     if (j.info[img].all_equal) return;
-    for (int k = threadIdx.x; k < 256 * kCopies; k += 256) sh[k] = 0;
+    for (int k = threadIdx.x; k < 128 * 32; k += 256) sh[k] = 0;
+    const int bank = threadIdx.x & 31;
+    auto hadd = [&](int k) { atomicAdd(&sh[(k >> 1) * 32 + bank], 1u << ((k & 1) * 16)); };
     const double* te = j.edges_g + (int64_t)img * kEdges;
     for (int k = threadIdx.x; k < kEdges; k += 256) st[k] = te[k];
     __syncthreads();
@@ -292,7 +298,6 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     const int64_t npix = (int64_t)j.H * j.W;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
-    const int cp = threadIdx.x & (kCopies - 1);
     uint32_t amb = 0;
     // bin estimate in float32 (v = g^0.4 by exp2/log2, then the uniform-bin formula); the exact bin is then fixed up by
     // compares against the edges, so the estimate only decides how many compares run
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
         k += (G >= e1) ? 1 : 0;
         k += (G >= e2) ? 1 : 0;
         if (G >= e2) { while (G >= sg[k + 1]) ++k; }        // dark pixels: bins narrower than a bucket (sg[256..] = inf ends it)
-        atomicAdd(&sh[k * kCopies + cp], 1u);
+        hadd(k);
         return (uint32_t)k;
     };
     uint8_t* bins = j.bins ? j.bins + (int64_t)img * npix : nullptr;   // bin plane for k_mask (integer path only)
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
         const int a = k < 1 ? 1 : k;
         const int b = k + 1 <= 255 ? k + 1 : 255;
         amb += near_rel(g, st[a]) || near_rel(g, st[b]);
-        atomicAdd(&sh[k * kCopies + cp], 1u);
+        hadd(k);
     };
     int64_t done = 0;
     if (integer_path) {
@@ -375,8 +380,8 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     }
     __syncthreads();
     uint32_t tot = 0;
-#pragma unroll
-    for (int c = 0; c < kCopies; ++c) tot += sh[threadIdx.x * kCopies + c];
+    for (int c = 0; c < 32; ++c)                                       // rotate the start so the 32 lanes of a group spread over the banks
+        tot += (sh[(threadIdx.x >> 1) * 32 + ((c + (threadIdx.x >> 1)) & 31)] >> ((threadIdx.x & 1) * 16)) & 0xffffu;
     if (tot) atomicAdd(&j.hist[(int64_t)img * j.hist_stride + threadIdx.x], tot);
     amb = wave_sum_u32(amb);
     if ((threadIdx.x & 63) == 0 && amb) atomicAdd(&j.info[img].ambiguous, amb);
@@ -564,7 +569,12 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
         const dim3 grid(blocks_per_image(j, 256 * 64), j.n);
         LFA_DISPATCH_V(k_minmax_rgb, grid, dim3(256), s, j);
         LFA_LAUNCH("k_edges_rgb", k_edges_rgb, dim3(j.n), dim3(320), 0, s, j);
-        LFA_DISPATCH_V(k_hist_rgb, grid, dim3(256), s, j);
+        {
+            // k_hist_rgb's 16-bit LDS counters: at most 2^21 pixels per block
+            const int64_t min_blocks = ((int64_t)j.H * j.W + (1 << 21) - 1) >> 21;
+            const dim3 gridh((unsigned)(grid.x > min_blocks ? grid.x : min_blocks), j.n);
+            LFA_DISPATCH_V(k_hist_rgb, gridh, dim3(256), s, j);
+        }
         LFA_LAUNCH("k_otsu_rgb", k_otsu_rgb, dim3(j.n), dim3(256), 0, s, j);
     } else if (j.dtype == LFA_U8) {
         hipError_t e = hipMemsetAsync(j.hist, 0, (size_t)j.n * j.hist_stride * sizeof(uint32_t), s);

@@ -1,0 +1,16 @@
+#!/bin/bash
+# End-of-round evidence run on the GPU box (from the repo root): parity tests, the default bench, the same bench under
+# rocprofv3 --kernel-trace --stats, the PMC passes, the secondary configurations.  Everything lands in gpurun_out/.
+set -e
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+cd $R
+timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/round_tests.log 2>&1
+tail -2 gpurun_out/round_tests.log
+timeout -k 10 300 python bench.py > gpurun_out/round_bench.log 2>&1
+cd /tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/round_prof -o r --output-format csv -- python3 $R/bench.py > $R/gpurun_out/round_prof_bench.log 2>&1
+cd $R
+bash tools/pmc_passes.sh > gpurun_out/round_pmc.log 2>&1
+timeout -k 10 300 python benchmarks_configs.py u16 rois gauss peaks > gpurun_out/round_secondary.log 2>&1
+echo done
