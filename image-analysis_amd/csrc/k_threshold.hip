@@ -280,17 +280,15 @@ __global__ void k_zero_hist_u16(Job j) {
 
 template <int V>
 __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
-    // 32 sub-histograms, one per LDS bank: lane l only ever touches bank l & 31, so the atomics of a wave never collide on
-    // a bank whatever the bins are.  Two 16-bit counters per dword (bins 2q, 2q+1) keep that at 16 KiB; a counter is
-    // fed by the 8 lanes of the block that share l & 31, so it stays below 2^16 while a block handles <= 2^21 pixels
-    // (launch_threshold sizes the grid accordingly).
-    __shared__ uint32_t sh[128 * 32];
+    // 16 sub-histograms: lane l adds into copy l & 15, i.e. word (bin << 4) | (l & 15); the 16 lanes with different copies
+    // sit on 16 different banks, two lanes with the same copy collide only when their bins have the same parity
+    __shared__ uint32_t sh[256 * 16];
     __shared__ double st[kEdges + 1];
     const int img = blockIdx.y;
     if (j.info[img].all_equal) return;
-    for (int k = threadIdx.x; k < 128 * 32; k += 256) sh[k] = 0;
-    const int bank = threadIdx.x & 31;
-    auto hadd = [&](int k) { atomicAdd(&sh[(k >> 1) * 32 + bank], 1u << ((k & 1) * 16)); };
+    for (int k = threadIdx.x; k < 256 * 16; k += 256) sh[k] = 0;
+    uint32_t* shl = sh + (threadIdx.x & 15);
+    auto hadd = [&](uint32_t k) { atomicAdd(&shl[k << 4], 1u); };
     const double* te = j.edges_g + (int64_t)img * kEdges;
     for (int k = threadIdx.x; k < kEdges; k += 256) st[k] = te[k];
     __syncthreads();
@@ -299,14 +297,18 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     uint32_t amb = 0;
-    // bin estimate in float32 (v = g^0.4 by exp2/log2, then the uniform-bin formula); the exact bin is then fixed up by
-    // compares against the edges, so the estimate only decides how many compares run
+    // float64 path only: bin estimate in float32 (v = g^0.4 by exp2/log2, then the uniform-bin formula), fixed up by
+    // compares against the edges
     const float vminf = (float)j.info[img].vmin;
     const float scalef = 256.0f / ((float)j.info[img].vmax - vminf);
     const uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
     const bool integer_path = eg[kEdgesI_Crit] == 0;
     __shared__ uint32_t sg[kEdges + 3];
-    __shared__ uint8_t tab[2496];                          // bin of G = b << 10, b = 0 .. 2490 (G <= 2 550 000)
+    // integer path: one table word per bucket of 1024 G values (G <= 2 550 000 < 2^22):
+    //   bits 0-7  bin of the bucket's first G,  bits 8-29  the next edge above it (clamped to 2^22-1 = never reached),
+    //   bit 31    a second edge lies inside the bucket as well (only for nearly black pixels, where bins are narrower
+    //             than a bucket) -> that pixel walks the edge list
+    __shared__ uint32_t tab[2496];
     if (integer_path) {
         for (int k = threadIdx.x; k < kEdges + 3; k += 256) sg[k] = (k < 256) ? eg[k] : kGInf;   // sentinel above bin 255
         __syncthreads();
@@ -320,19 +322,18 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
                 lo = ge ? mid : lo;
                 hi = ge ? hi : mid - 1;
             }
-            tab[b] = (uint8_t)lo;
+            const uint32_t e1 = sg[lo + 1] < 0x3fffffu ? sg[lo + 1] : 0x3fffffu;
+            const uint32_t two = (sg[lo + 2] <= G0 + 1023u) ? 0x80000000u : 0u;
+            tab[b] = (uint32_t)lo | (e1 << 8) | two;
         }
         __syncthreads();
     }
-    auto addG = [&](uint32_t G) -> uint32_t {              // integer path: see g_threshold
-        int k = tab[G >> 10];                               // bin of the bucket start: a lower bound
-        const uint32_t e1 = sg[k + 1], e2 = sg[k + 2];      // one LDS access for the two next edges
-        k += (G >= e1) ? 1 : 0;
-        k += (G >= e2) ? 1 : 0;
-        if (G >= e2) { while (G >= sg[k + 1]) ++k; }        // dark pixels: bins narrower than a bucket (sg[256..] = inf ends it)
-        hadd(k);
-        return (uint32_t)k;
+    auto binG = [&](uint32_t G, uint32_t& flags) -> uint32_t {   // bin unless the bucket is flagged (then a lower bound)
+        const uint32_t ent = tab[G >> 10];
+        flags |= ent;
+        return (ent & 0xffu) + ((G >= ((ent >> 8) & 0x3fffffu)) ? 1u : 0u);
     };
+    auto walk = [&](uint32_t G, uint32_t k) -> uint32_t { while (G >= sg[k + 1]) ++k; return k; };   // sg[256..] = inf ends it
     uint8_t* bins = j.bins ? j.bins + (int64_t)img * npix : nullptr;   // bin plane for k_mask (integer path only)
     auto add = [&](double g) {                             // float64 path (an edge is critical): exact compares + census
         const float vf = __builtin_amdgcn_exp2f(0.4f * __builtin_amdgcn_logf((float)g));
@@ -353,15 +354,25 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
             for (int64_t g = tid; g < ng; g += nth) {
                 uint32_t w[12];
                 load48(base + g * 48, w);
+                uint32_t G[16], kb[16], flags = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { G[k] = gray_G16(w, k); kb[k] = binG(G[k], flags); }
+                if ((int)flags < 0) {                                 // some pixel of the group is in a two-edge bucket
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) kb[k] = walk(G[k], kb[k]);
+                }
                 uint32_t pk[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int k = 0; k < 16; ++k) pk[k >> 2] |= addG(gray_G16(w, k)) << (8 * (k & 3));
+                for (int k = 0; k < 16; ++k) { hadd(kb[k]); pk[k >> 2] |= kb[k] << (8 * (k & 3)); }
                 if (bins) *(uint4*)(bins + g * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
             }
             done = ng << 4;
         }
         for (int64_t p = done + tid; p < npix; p += nth) {
-            const uint32_t k = addG(gray_G(base[3 * p], base[3 * p + 1], base[3 * p + 2]));
+            uint32_t flags = 0;
+            const uint32_t G = gray_G(base[3 * p], base[3 * p + 1], base[3 * p + 2]);
+            const uint32_t k = walk(G, binG(G, flags));
+            hadd(k);
             if (bins) bins[p] = (uint8_t)k;
         }
     } else {
@@ -380,8 +391,8 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     }
     __syncthreads();
     uint32_t tot = 0;
-    for (int c = 0; c < 32; ++c)                                       // rotate the start so the 32 lanes of a group spread over the banks
-        tot += (sh[(threadIdx.x >> 1) * 32 + ((c + (threadIdx.x >> 1)) & 31)] >> ((threadIdx.x & 1) * 16)) & 0xffffu;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) tot += sh[(threadIdx.x << 4) + ((c + threadIdx.x) & 15)];     // rotated: spreads the lanes over the banks
     if (tot) atomicAdd(&j.hist[(int64_t)img * j.hist_stride + threadIdx.x], tot);
     amb = wave_sum_u32(amb);
     if ((threadIdx.x & 63) == 0 && amb) atomicAdd(&j.info[img].ambiguous, amb);
@@ -569,12 +580,7 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
         const dim3 grid(blocks_per_image(j, 256 * 64), j.n);
         LFA_DISPATCH_V(k_minmax_rgb, grid, dim3(256), s, j);
         LFA_LAUNCH("k_edges_rgb", k_edges_rgb, dim3(j.n), dim3(320), 0, s, j);
-        {
-            // k_hist_rgb's 16-bit LDS counters: at most 2^21 pixels per block
-            const int64_t min_blocks = ((int64_t)j.H * j.W + (1 << 21) - 1) >> 21;
-            const dim3 gridh((unsigned)(grid.x > min_blocks ? grid.x : min_blocks), j.n);
-            LFA_DISPATCH_V(k_hist_rgb, gridh, dim3(256), s, j);
-        }
+        LFA_DISPATCH_V(k_hist_rgb, grid, dim3(256), s, j);
         LFA_LAUNCH("k_otsu_rgb", k_otsu_rgb, dim3(j.n), dim3(256), 0, s, j);
     } else if (j.dtype == LFA_U8) {
         hipError_t e = hipMemsetAsync(j.hist, 0, (size_t)j.n * j.hist_stride * sizeof(uint32_t), s);
