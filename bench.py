@@ -89,11 +89,19 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # LFA_BENCH_REHEARSAL=1 (tests only): ranks share the GPUs there are and talk over gloo, so that the multi-rank code
+    # path can be exercised on a one-GPU box; the real run is one rank per GPU over RCCL ("nccl" IS RCCL on ROCm)
+    rehearsal = os.environ.get("LFA_BENCH_REHEARSAL") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = torch.device("cpu") if rehearsal else dev          # where the few collective operands live
 
     capi = importlib.import_module("image_analysis_amd._capi")
     synth = importlib.import_module("image_analysis_amd.synth")
@@ -117,7 +125,7 @@ def main():
     # one handle + one stream per lane of the chunk pipeline: the latency-bound tail kernels of one chunk overlap with
     # the streaming kernels of the next (per-device streams, no cross-stream dependency: chunks are independent)
     NS = max(1, min(args.streams, (B + CH - 1) // CH))
-    engs = [capi.Engine(device=local_rank, max_h=H, max_w=W, max_c=3, max_batch=CH) for _ in range(NS)]
+    engs = [capi.Engine(device=dev_index, max_h=H, max_w=W, max_c=3, max_batch=CH) for _ in range(NS)]
     eng = engs[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     strips = capi.dev_bytes(B * max_strips * capi.STRIP_DT.itemsize, dev)
@@ -170,7 +178,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -194,6 +202,7 @@ def main():
     cn = counts.cpu().numpy()
     n_peaks = int(sum(int(pk[i, :cn[i]]["n_peaks"].sum()) for i in range(0, B, max(1, B // 64))))
     if world > 1:
+        n_strips = n_strips.to(cdev)
         dist.all_reduce(n_strips, op=dist.ReduceOp.SUM)
     total_strips = int(n_strips.item())
 
