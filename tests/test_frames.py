@@ -1,0 +1,95 @@
+"""File readers and the frame pipeline in front of the device path.
+
+CPU part: imread / iter_tiff_pages on files written here with PIL (lossless: TIFF, PNG), shapes, dtypes and channel
+order as detection.py:454 would deliver them.  GPU part: analyze_stream == the oracle frame by frame, in order, across
+batch boundaries."""
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import lfa_oracle as O
+
+
+def _write_stack(path, frames):
+    ims = [Image.fromarray(f) for f in frames]
+    ims[0].save(path, save_all=True, append_images=ims[1:])
+
+
+def test_tiff_stack_pages_round_trip(tmp_path):
+    from image_analysis_amd import frames as F
+    rng = np.random.default_rng(1)
+    stack = [rng.integers(0, 4096, size=(48, 64), dtype=np.uint16) for _ in range(5)]
+    p = str(tmp_path / "stack.tif")
+    _write_stack(p, stack)
+    pages = list(F.iter_tiff_pages(p))
+    assert len(pages) == 5 and all(a.dtype == np.uint16 and a.flags.c_contiguous for a in pages)
+    assert all(np.array_equal(a, b) for a, b in zip(pages, stack))
+    assert np.array_equal(F.imread(p), np.stack(stack))                  # tifffile.imread stacks the pages
+    one = str(tmp_path / "one.tiff")
+    Image.fromarray(stack[0]).save(one)
+    assert np.array_equal(F.imread(one), stack[0]) and F.imread(one).ndim == 2
+
+
+def test_imread_colour_is_bgr_and_grey_is_three_channels(tmp_path):
+    from image_analysis_amd import frames as F
+    rng = np.random.default_rng(2)
+    rgb = rng.integers(0, 256, size=(20, 30, 3), dtype=np.uint8)
+    p = str(tmp_path / "c.png")
+    Image.fromarray(rgb).save(p)
+    got = F.imread(p)
+    assert got.dtype == np.uint8 and got.flags.c_contiguous and np.array_equal(got, rgb[:, :, ::-1])
+    g = rng.integers(0, 256, size=(20, 30), dtype=np.uint8)
+    pg = str(tmp_path / "g.png")
+    Image.fromarray(g).save(pg)
+    got = F.imread(pg)                                                   # cv2.imread default flag: IMREAD_COLOR
+    assert got.shape == (20, 30, 3) and all(np.array_equal(got[:, :, c], g) for c in range(3))
+
+
+def _check_frame(frame, strips, profiles, peaks):
+    mm_c = int(frame.shape[1] / 40)
+    mm_r = mm_c * 20
+    d = O.detect_debug(frame, mm_r, mm_c, 10)
+    assert [[int(s["minr"]), int(s["maxr"]), int(s["minc"]), int(s["maxc"])] for s in strips] == d["strips"]
+    for k, box in enumerate(d["strips"]):
+        wp, wk = O.image_analysis(frame[box[0]:box[1], box[2]:box[3]], False)
+        assert np.array_equal(profiles[k], wp)
+        assert peaks[k]["n_peaks"] == len(wk)
+        for i, (s, e, a) in enumerate(wk):
+            assert (peaks[k]["start"][i], peaks[k]["end"][i]) == (s, e) and peaks[k]["area"][i] == a
+    return len(d["strips"])
+
+
+@pytest.mark.gpu
+def test_analyze_stream_tiff_stack_matches_oracle(tmp_path):
+    from image_analysis_amd import frames as F
+    from image_analysis_amd.synth import synth_u16
+    stack = [synth_u16(512, 512, 8, 300 + i) for i in range(5)]
+    p = str(tmp_path / "stack.tif")
+    _write_stack(p, stack)
+    seen, total = [], 0
+    for idx, strips, profiles, peaks in F.analyze_stream(F.iter_tiff_pages(p), batch=2):     # batches of 2, 2, 1
+        seen.append(idx)
+        total += _check_frame(stack[idx], strips, profiles, peaks)
+    assert seen == [0, 1, 2, 3, 4] and total >= 5
+
+
+@pytest.mark.gpu
+def test_analyze_stream_colour_files_and_errors(tmp_path):
+    from image_analysis_amd import frames as F
+    from image_analysis_amd.synth import synth_rgb
+    paths = []
+    for i in range(3):
+        p = str(tmp_path / f"img{i}.png")
+        Image.fromarray(synth_rgb(384, 512, 6, 40 + i)[:, :, ::-1].copy()).save(p)       # file holds RGB; imread returns BGR
+        paths.append(p)
+    frames = [F.imread(p) for p in paths]
+    assert all(np.array_equal(f, synth_rgb(384, 512, 6, 40 + i)) for i, f in enumerate(frames))
+    out = list(F.analyze_stream(iter(frames), batch=8))
+    assert [o[0] for o in out] == [0, 1, 2]
+    for idx, strips, profiles, peaks in out:
+        assert _check_frame(frames[idx], strips, profiles, peaks) >= 3
+    assert list(F.analyze_stream(iter([]))) == []
+    with pytest.raises(ValueError):
+        list(F.analyze_stream(iter([frames[0], frames[1][:100]]), batch=4))
+    with pytest.raises(TypeError):
+        list(F.analyze_stream(iter([frames[0].astype(np.float32)])))
