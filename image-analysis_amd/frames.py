@@ -65,7 +65,7 @@ def imread(path) -> np.ndarray:
     return np.ascontiguousarray(a[:, :, ::-1])
 
 
-def analyze_stream(frames, batch=16, device=0, line_length=10, max_strips=64, min_maxr=None, min_maxc=None):
+def analyze_stream(frames, batch=16, device=0, line_length=10, max_strips=64, min_maxr=None, min_maxc=None, pack_threads=8):
     """detect + image_analysis(strip, False) for every frame of an iterable of equally shaped uint8/uint16 frames.
 
     Yields, in input order, one `(frame_index, strips, profiles, peaks)` per frame: `strips` a STRIP_DT array, `profiles`
@@ -130,28 +130,38 @@ def analyze_stream(frames, batch=16, device=0, line_length=10, max_strips=64, mi
         slot["out"] = slot["host_out"] = None
         return res
 
+    from concurrent.futures import ThreadPoolExecutor
+    packers = ThreadPoolExecutor(max_workers=max(1, int(pack_threads)))
+
+    def pack(slot, group, index0):
+        """copy the frames of one batch into the slot's pinned buffer (numpy releases the GIL: the copies run in parallel)"""
+        def one(q):
+            a = np.asarray(group[q])
+            if a.shape != first.shape or a.dtype != first.dtype:
+                raise ValueError(f"frame {index0 + q}: shape/dtype {a.shape}/{a.dtype} differs from the first frame's")
+            slot["host"][q].numpy()[:] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        list(packers.map(one, range(len(group))))
+
     try:
-        cur, filled, index0, nxt = 0, 0, 0, first
+        cur, index0, nxt = 0, 0, first
         pending = []                                               # slots in flight, oldest first
         while nxt is not None:
+            group = []
+            while nxt is not None and len(group) < batch:
+                group.append(nxt)
+                nxt = next(it, None)
             slot = slots[cur]
             if slot["busy"]:                                       # its previous batch must be out before the buffer is reused
                 pending.remove(slot)
                 yield from collect(slot)
-            a = np.asarray(nxt)
-            if a.shape != first.shape or a.dtype != first.dtype:
-                raise ValueError(f"frame {index0 + filled}: shape/dtype {a.shape}/{a.dtype} differs from the first frame's")
-            slot["host"][filled].numpy()[:] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
-            filled += 1
-            nxt = next(it, None)
-            if filled == batch or nxt is None:
-                launch(slot, filled, index0)
-                pending.append(slot)
-                index0 += filled
-                filled = 0
-                cur ^= 1
+            pack(slot, group, index0)
+            launch(slot, len(group), index0)
+            pending.append(slot)
+            index0 += len(group)
+            cur ^= 1
         for slot in pending:
             yield from collect(slot)
     finally:
+        packers.shutdown(wait=True)
         torch.cuda.synchronize(dev)
         eng.close()
