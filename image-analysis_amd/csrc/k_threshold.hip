@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Otsu, integer path.  One 256-thread block per image.  All sums are exact integers (counts < 2^24, so the
+// Otsu, integer path.  One 256-thread block per image.  Up to 2^24 pixels all sums are exact integers (so the
 // reference's float32 cumsums are exact too); the only floating-point steps are the two divisions, the float32
 // product w1*w2 and the final float64 product, done per candidate in the reference's order.
 // ------------------------------------------------------------------------------------------------------------------
@@ -433,6 +433,37 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
     }
     const int seg = (nb + 255) / 256;
     const int b0 = t * seg, b1 = min(nb, b0 + seg);
+    double bv = -1.0; int bi = -1;
+    if ((int64_t)j.H * j.W > (1 << 24)) {
+        // more than 2^24 pixels: the reference's float32 weights round, in bin order (lfa_algo.h otsu_seq_*).  Lane 0 walks
+        // the histogram upwards and lane 64 downwards, tile by tile through LDS; then every thread prices the splits of
+        // its own segment from the four prefix arrays.
+        constexpr int T = 1024;
+        __shared__ uint32_t cf[T], cb[T];
+        __shared__ int32_t lf[T + 1], lb[T + 1];
+        float* w1 = j.otsu_w + (int64_t)img * 2 * j.hist_stride; float* w2 = w1 + j.hist_stride;
+        double* s1 = j.otsu_s + (int64_t)img * 2 * j.hist_stride; double* s2 = s1 + j.hist_stride;
+        OtsuSeq sf{0.0f, 0.0, 0}, sb{0.0f, 0.0, 0};
+        const int ntiles = (nb + T - 1) / T;
+        for (int it = 0; it < ntiles; ++it) {
+            const int f0 = it * T, fn = min(T, nb - f0);
+            const int r0 = (ntiles - 1 - it) * T, rn = min(T, nb - r0);
+            for (int k = t; k < fn; k += 256) { cf[k] = gh[base_bin + f0 + k]; lf[k] = lut(xmin + f0 + k); }
+            for (int k = t; k < rn; k += 256) { cb[k] = gh[base_bin + r0 + k]; lb[k + 1] = lut(xmin + r0 + k); }
+            if (t == 0) { lf[fn] = (f0 + fn < nb) ? lut(xmin + f0 + fn) : -1; lb[0] = (r0 > 0) ? lut(xmin + r0 - 1) : -1; }
+            __syncthreads();
+            if (t == 0) otsu_seq_fwd(cf, lf, fn, sf, w1 + f0, s1 + f0);
+            if (t == 64) otsu_seq_bwd(cb, lb, rn, sb, w2 + r0, s2 + r0);
+            __syncthreads();
+        }
+        __threadfence();
+        __syncthreads();
+        for (int b = b0; b < b1; ++b)
+            if (b < nb - 1 && lut(xmin + b + 1) != lut(xmin + b)) {
+                const double var = otsu_seq_variance(w1[b], s1[b], w2[b + 1], s2[b + 1]);
+                if (bi < 0 || var > bv) { bv = var; bi = b; }
+            }
+    } else {
     unsigned long long w = 0, s = 0;
     for (int b = b0; b < b1; ++b) {
         const unsigned long long c = gh[base_bin + b];
@@ -454,7 +485,6 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
     __syncthreads();
     const unsigned long long totw = s_totw, tots = s_tots;
     unsigned long long cw = s_w[t], cs = s_s[t];
-    double bv = -1.0; int bi = -1;
     for (int b = b0; b < b1; ++b) {
         const unsigned long long c = gh[base_bin + b];
         const int v = lut(xmin + b);
@@ -468,6 +498,7 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
             const double var = (double)ww * (d * d);
             if (bi < 0 || var > bv) { bv = var; bi = b; }
         }
+    }
     }
     s_bv[t] = bv; s_bi[t] = bi;
     __syncthreads();

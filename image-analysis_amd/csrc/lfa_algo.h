@@ -260,5 +260,54 @@ LFA_HD int otsu_float256(const uint32_t* cnt, double vmin, double vmax, double* 
     return best;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// threshold_otsu on an INTEGER image with more than 2^24 pixels (thresholding.py:309, :365-381).  The reference casts the
+// per-value counts to float32 and accumulates them in float32, one bin after the other; beyond 2^24 those sums round,
+// and the result depends on that order.  The histogram here is over input values x; the reference's is over gamma
+// values v = lut[x], so the count of a gamma bin is the (exact) sum over the run of x that share v, cast to float32
+// once, at the end of the run.  `lv[b]` is the gamma value of bin b; a run ends where lv changes.
+//   forward : w[b] = weight1 and s[b] = cumsum(counts*centers) after the run containing b ... valid at run ends
+//   backward: the same from the top, valid at run starts
+// The products fl32(count) * v are integers below 2^53, so the float64 sums are exact whatever their order.
+// ---------------------------------------------------------------------------------------------------------------
+struct OtsuSeq { float a; double sa; unsigned long long gc; };
+
+// cnt[0..n), lv[0..n]: lv[n] is the gamma value of the bin after this tile (or -1 after the last bin)
+LFA_HD void otsu_seq_fwd(const uint32_t* cnt, const int32_t* lv, int n, OtsuSeq& st, float* w, double* s) {
+    for (int b = 0; b < n; ++b) {
+        st.gc += cnt[b];
+        if (lv[b + 1] != lv[b]) {
+            const float c = (float)st.gc;
+            st.a = st.a + c;
+            st.sa = st.sa + (double)c * (double)lv[b];
+            st.gc = 0;
+        }
+        w[b] = st.a; s[b] = st.sa;
+    }
+}
+
+// cnt[0..n), lvm[0..n]: lvm[b + 1] is the gamma value of bin b, lvm[0] that of the bin before this tile (or -1 before bin 0)
+LFA_HD void otsu_seq_bwd(const uint32_t* cnt, const int32_t* lvm, int n, OtsuSeq& st, float* w, double* s) {
+    for (int b = n - 1; b >= 0; --b) {
+        st.gc += cnt[b];
+        if (lvm[b] != lvm[b + 1]) {
+            const float c = (float)st.gc;
+            st.a = st.a + c;
+            st.sa = st.sa + (double)c * (double)lvm[b + 1];
+            st.gc = 0;
+        }
+        w[b] = st.a; s[b] = st.sa;
+    }
+}
+
+// between-class variance of the split after bin b (a run end): weight1/mean1 at b, weight2/mean2 at b + 1
+LFA_HD double otsu_seq_variance(float w1, double s1, float w2, double s2) {
+    const double m1 = s1 / (double)w1;
+    const double m2 = s2 / (double)w2;
+    const float ww = w1 * w2;
+    const double d = m1 - m2;
+    return (double)ww * (d * d);
+}
+
 }  // namespace lfa
 #endif  // LFA_ALGO_H_

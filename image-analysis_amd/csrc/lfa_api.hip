@@ -78,13 +78,13 @@ struct LfaContext {
     int max_h = 0, max_w = 0, max_c = 0, max_batch = 0;
     int gray_variant = LFA_GRAY_FMA_102;
     int debug_flags = 0;
-    Buf info, hist, edges, edges_i, bins, maskT, col_cnt, run_se, run_col, parent, area, bbox, firstbits, wordrank, root_of_label, cand,
+    Buf info, hist, otsu_w, otsu_s, edges, edges_i, bins, maskT, col_cnt, run_se, run_col, parent, area, bbox, firstbits, wordrank, root_of_label, cand,
         cand_sum, cand_rs_off, rowsum, slot_rs_off, lut8, lut16, rois;
     lfa::Job last{};
     bool have_last = false;
     EventTimer* timer = nullptr;
     std::vector<Buf*> all() {
-        return {&info, &hist, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &firstbits, &wordrank,
+        return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &firstbits, &wordrank,
                 &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &lut8, &lut16, &rois};
     }
 };
@@ -123,6 +123,10 @@ int ensure_workspace(LfaContext* h, int n, int H, int W, int C, int dtype, int L
     int rc;
     if ((rc = ensure(h->info, N * sizeof(LfaImageInfo)))) return rc;
     if ((rc = ensure(h->hist, N * hist_stride * 4))) return rc;
+    if (C == 1 && (size_t)H * W > ((size_t)1 << 24)) {          // float32-rounded Otsu weights (k_otsu_int)
+        if ((rc = ensure(h->otsu_w, N * 2 * hist_stride * 4))) return rc;
+        if ((rc = ensure(h->otsu_s, N * 2 * hist_stride * 8))) return rc;
+    }
     if ((rc = ensure(h->edges, N * lfa::kEdges * 8))) return rc;
     if ((rc = ensure(h->edges_i, N * lfa::kEdgesI * 4))) return rc;
     if (C == 3 && (rc = ensure(h->bins, N * (size_t)H * W))) return rc;
@@ -175,6 +179,8 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.info = (LfaImageInfo*)h->info.p;
     j.hist = (uint32_t*)h->hist.p;
     j.hist_stride = (dtype == LFA_U16) ? lfa::kHistBinsU16 : 256;
+    j.otsu_w = (float*)h->otsu_w.p;
+    j.otsu_s = (double*)h->otsu_s.p;
     j.edges_g = (double*)h->edges.p;
     j.edges_i = (uint32_t*)h->edges_i.p;
     // bin plane: colour images on the vector paths only (16-pixel groups in k_hist_rgb, 16-column groups in k_mask)
@@ -208,9 +214,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (rc) return rc;
     if (C == 3 && dtype != LFA_U8) return fail(LFA_ERR_UNSUPPORTED, "colour images must be uint8 (uint16 colour is not implemented)");
     if (H > 65535 || W > 65535) return fail(LFA_ERR_ARG, "image sides above 65535 are not supported");
-    if ((long long)H * W > (1ll << 24))
-        return fail(LFA_ERR_UNSUPPORTED, "images above 2^24 pixels are not supported: the reference's float32 histogram weights "
-                                         "(skimage thresholding.py:309) stop being exact there");
+    if ((long long)H * W > (1ll << 30)) return fail(LFA_ERR_UNSUPPORTED, "images above 2^30 pixels are not supported");
     if (L < 1) return fail(LFA_ERR_ARG, "line_length must be >= 1");
     if (min_maxr < 0 || min_maxc < 0) return fail(LFA_ERR_ARG, "min_maxr/min_maxc must be >= 0");
     if (!out_strips || !out_counts) return fail(LFA_ERR_ARG, "null output pointer");

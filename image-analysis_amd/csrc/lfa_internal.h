@@ -40,6 +40,8 @@ struct Job {
     LfaImageInfo* info;      // [n]
     uint32_t* hist;          // [n][65536]      (uint16)  or [n][256]
     int32_t hist_stride;
+    float* otsu_w;           // [n][2][hist_stride]  float32 weight1 / weight2 prefix arrays, images above 2^24 pixels only
+    double* otsu_s;          // [n][2][hist_stride]  the matching cumsum(counts*centers) arrays
     double* edges_g;         // [n][257]  gray-space bin edges (colour path)
     uint32_t* edges_i;       // [n][264]  the same as integer thresholds on G = 2125*b0 + 7154*b1 + 721*b2 (k_threshold.hip)
     uint8_t* bins;           // [n][H*W]  colour path: histogram bin of every pixel, written by k_hist_rgb and read by k_mask

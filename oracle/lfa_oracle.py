@@ -108,18 +108,24 @@ def histogram_image_range(image: np.ndarray, nbins: int = 256):
     return counts, (edges[:-1] + edges[1:]) / 2.0
 
 
-def threshold_otsu(image: np.ndarray, nbins: int = 256):
-    first = image.reshape(-1)[0]
-    if np.all(image == first):
-        return first
-    counts, centers = histogram_image_range(image, nbins)
-    counts = counts.astype("float32", copy=False)
+def otsu_from_hist(counts, centers):
+    """thresholding.py:365-381 on a histogram (counts, bin_centers): the threshold and the index of its bin."""
+    counts = np.asarray(counts).astype("float32", copy=False)
     weight1 = np.cumsum(counts)
     weight2 = np.cumsum(counts[::-1])[::-1]
     mean1 = np.cumsum(counts * centers) / weight1
     mean2 = (np.cumsum((counts * centers)[::-1]) / weight2[::-1])[::-1]
     variance12 = weight1[:-1] * weight2[1:] * (mean1[:-1] - mean2[1:]) ** 2
-    return centers[np.argmax(variance12)]
+    idx = int(np.argmax(variance12))
+    return centers[idx], idx
+
+
+def threshold_otsu(image: np.ndarray, nbins: int = 256):
+    first = image.reshape(-1)[0]
+    if np.all(image == first):
+        return first
+    counts, centers = histogram_image_range(image, nbins)
+    return otsu_from_hist(counts, centers)[0]
 
 
 # --------------------------------------------------------------------------------------------------

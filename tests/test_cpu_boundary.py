@@ -148,6 +148,34 @@ def test_device_sum_and_linspace_match_numpy(hc):
         assert all(hc.hc_linspace_at(a, b, n, i) == ref[i] for i in range(n))
 
 
+def test_device_big_image_int_otsu_matches_oracle(hc):
+    """Integer-image Otsu with float32-rounded weights (images above 2^24 pixels): the shared sequential code against the
+    oracle's thresholding.py restatement on histograms whose counts reach 2^31 in total, with a gamma table that merges
+    neighbouring input values into one bin and leaves gamma bins empty."""
+    from oracle import lfa_oracle as O
+    rng = np.random.default_rng(5)
+    hc.hc_otsu_int_seq.restype = C.c_int
+    hc.hc_otsu_int_seq.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    for trial in range(40):
+        nb = int(rng.integers(2, 3000))
+        scale = 10 ** int(rng.integers(3, 7))
+        cnt = (rng.random(nb) ** 3 * scale).astype(np.uint32)
+        if trial % 3 == 0:                                            # two far modes of very different weight
+            cnt[: nb // 3] *= 50
+        cnt[0] = max(cnt[0], 1); cnt[-1] = max(cnt[-1], 1)            # xmin and xmax are occupied by definition
+        gamma = float(rng.choice([0.4, 1.0, 2.0]))
+        x = np.arange(nb) + int(rng.integers(0, 100))
+        lv = np.floor(((x / x.max()) ** gamma) * x.max()).astype(np.int32)   # non-decreasing, with ties and gaps
+        # the reference's histogram: one bin per gamma value from lv.min() to lv.max()
+        vmin, vmax = int(lv.min()), int(lv.max())
+        if vmin == vmax:
+            continue
+        counts = np.bincount(lv - vmin, weights=cnt.astype(np.float64), minlength=vmax - vmin + 1).astype(np.int64)
+        want_v, _ = O.otsu_from_hist(counts, np.arange(vmin, vmax + 1))
+        b = hc.hc_otsu_int_seq(cnt.ctypes.data, lv.ctypes.data, nb)
+        assert b >= 0 and int(lv[b]) == int(want_v), (trial, nb, scale, gamma)
+
+
 def test_device_float_otsu_matches_oracle(hc):
     from oracle import lfa_oracle as O
     rng = np.random.default_rng(5)

@@ -55,6 +55,24 @@ def test_config4_size_colour_3072x4096():
     assert len(res[0][0]) == 8
 
 
+@pytest.mark.parametrize("kind", ["colour", "uint8", "uint16"])
+def test_images_above_2_24_pixels(kind):
+    """More than 2^24 pixels: skimage's float32 histogram weights (thresholding.py:309) are no longer exact and round in
+    bin order; the colour path restates that order anyway, the integer path switches to the sequential float32 walk
+    (lfa_algo.h otsu_seq_*, pinned on the host against the oracle with far larger counts)."""
+    from image_analysis_amd.synth import synth_rgb, synth_u16
+    H, W = 4104, 4112                                      # 16.88 M pixels
+    if kind == "colour":
+        img = synth_rgb(H, W, 8, 7)
+    elif kind == "uint8":
+        img = np.ascontiguousarray(synth_rgb(H, W, 8, 8)[:, :, 1])
+    else:
+        img = synth_u16(H, W, 40, 9)
+    assert img.shape[0] * img.shape[1] > (1 << 24)
+    res, info = _check_full(img[None], 1)
+    assert len(res[0][0]) >= 8
+
+
 def test_batch_properties_and_determinism():
     """A tiled batch must give every copy of an image the same answer, twice in a row (atomics / union-find order
     must not leak into results), and flipping an image left-right must mirror the strip columns."""
