@@ -93,3 +93,35 @@ def test_analyze_stream_colour_files_and_errors(tmp_path):
         list(F.analyze_stream(iter([frames[0], frames[1][:100]]), batch=4))
     with pytest.raises(TypeError):
         list(F.analyze_stream(iter([frames[0].astype(np.float32)])))
+
+
+def test_profile_csv_has_the_reference_sheet_layout_and_round_trips(tmp_path, golden_dir):
+    import os
+    from image_analysis_amd import export as E
+    ka = np.load(os.path.join(golden_dir, "excel2_known_answer.npz"))
+    prof = ka["profile_column_B"]                          # column B of the sheet the reference itself wrote
+    p = str(tmp_path / "p.csv")
+    E.write_profile_csv(p, prof)
+    lines = open(p).read().splitlines()
+    assert lines[0] == ",Intensity" and lines[1].startswith("0,") and len(lines) == len(prof) + 1
+    assert np.array_equal(E.read_profile_csv(p), prof)     # bit-exact through text
+
+
+def test_batch_csv_tables(tmp_path):
+    import csv
+    from image_analysis_amd import export as E
+    import image_analysis_amd._capi as capi
+    strips = np.zeros(2, capi.STRIP_DT)
+    strips["minr"], strips["maxr"], strips["minc"], strips["maxc"], strips["area"] = [1, 2], [11, 12], [3, 4], [8, 9], [50, 60]
+    peaks = np.zeros(2, capi.PEAKS_DT)
+    peaks["n_peaks"] = [2, 1]
+    peaks["start"][0], peaks["end"][0], peaks["area"][0] = [1, 5], [3, 7], [0.1, 2.5]
+    peaks["start"][1][0], peaks["end"][1][0], peaks["area"][1][0] = 2, 4, 1 / 3
+    profs = [np.array([1.5, 2.25, 1 / 3]), np.array([4.0])]
+    n = E.write_batch_csv(str(tmp_path / "pr.csv"), str(tmp_path / "su.csv"), [(7, strips, profs, peaks)])
+    assert n == 2
+    pr = list(csv.reader(open(tmp_path / "pr.csv")))
+    su = list(csv.reader(open(tmp_path / "su.csv")))
+    assert len(pr) == 1 + 4 and pr[3] == ["7", "0", "2", repr(1 / 3)]
+    assert su[1][:8] == ["7", "0", "1", "11", "3", "8", "50", "2"] and float(su[1][13]) == 2.5
+    assert su[2][7] == "1" and su[2][11:] == ["", "", ""] and float(su[2][10]) == 1 / 3
