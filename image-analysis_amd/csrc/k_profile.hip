@@ -13,9 +13,27 @@ namespace lfa {
 
 // np.argmax / np.argmin over p[0..n): first extremum, first NaN wins.  Called by the G lanes of one group (G = 16 or 64
 // consecutive lanes of a wave) with identical arguments; other groups of the wave may run other profiles.
+// The walk from the extremum to a foot of the peak (lfa_algo.h walk_goes_on), G positions per step: lane k of the group
+// tests position from + dir*(step*G + k); the first position where the walk stops is the answer.  Every lane of the group
+// calls this with identical arguments and gets the same result.
+template <int G>
+struct GroupWalk {
+    __device__ __forceinline__ int operator()(const double* p, int n, int from, int dir, double thr, bool inverse) const {
+        const int lane = threadIdx.x & 63, lg = lane & (G - 1), gshift = lane & ~(G - 1);
+        for (int base = from;; base += dir * G) {
+            const int i = base + dir * lg;
+            const bool inside = i >= 0 && i < n;
+            const bool stop = !inside || !walk_goes_on(p, n, i, dir, thr, inverse);
+            const unsigned long long bal = __ballot(stop);
+            const unsigned long long mine = (G == 64) ? bal : ((bal >> gshift) & ((1ull << (G & 63)) - 1ull));
+            if (mine) return base + dir * (int)__builtin_ctzll(mine);
+        }
+    }
+};
+
 template <int G>
 struct GroupArgExt {
-    __device__ int operator()(const double* p, int n, bool want_min) const {
+    __device__ __forceinline__ int operator()(const double* p, int n, bool want_min) const {
         const int lg = threadIdx.x & (G - 1);
         double m = 0.0; int idx = 0x7fffffff; bool isn = false;
         for (int i = lg; i < n; i += G) {
@@ -227,6 +245,27 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
     if (bad && lg == 0) store_bad(&peaks[ri], len);               // k_peaks skips ROIs it finds bad by the same test
 }
 
+// the peak search of one profile, run by the G lanes of its group with identical arguments; `dst` non-null on one lane
+template <int G>
+__device__ __forceinline__ void peaks_search(const double* p, int len, int inverse, int window, int two, int rng, LfaPeaks* dst) {
+    TwoPeaks tp;
+    if (two) {
+        tp = two_peaks_t(p, len, inverse != 0, rng, inverse == 0, window, GroupArgExt<G>(), GroupWalk<G>());
+    } else {
+        tp.n = 0;
+        if (len > 0) {
+            const int pk = GroupArgExt<G>()(p, len, inverse != 0);
+            tp.n = 1; tp.pk[0] = analyze_peaks_at_t(p, len, pk, inverse != 0, window, GroupWalk<G>()); tp.pk[1] = tp.pk[0];
+        }
+    }
+    if (dst) store_peaks(dst, tp, len);
+}
+
+template <int G>
+__device__ __noinline__ void peaks_search_global(const double* p, int len, int inverse, int window, int two, int rng, LfaPeaks* dst) {
+    peaks_search<G>(p, len, inverse, window, two, rng, dst);
+}
+
 // analyze_peaks / the two-peak logic on profiles in global memory: G lanes per profile, profiles staged in LDS.
 // Lengths come from `lengths` (lfa_peaks_batch) or from the ROI list the profiles were computed for (rois != null).
 template <int G>
@@ -262,18 +301,10 @@ __global__ __launch_bounds__(256) void k_peaks(const double* profiles, const int
     __syncthreads();
     if (bad) { if (lg == 0) store_bad(&out[i], len); return; }
     if (!work) return;
-    const double* p = use_lds ? sp : g;
-    TwoPeaks tp;
-    if (two) {
-        tp = two_peaks_t(p, len, inverse != 0, rng, inverse == 0, window, GroupArgExt<G>());
-    } else {
-        tp.n = 0;
-        if (len > 0) {
-            const int pk = GroupArgExt<G>()(p, len, inverse != 0);
-            tp.n = 1; tp.pk[0] = analyze_peaks_at(p, len, pk, inverse != 0, window); tp.pk[1] = tp.pk[0];
-        }
-    }
-    if (lg == 0) store_peaks(&out[i], tp, len);
+    // the search is inlined for the LDS copy of the profile (ds_read on the dependent chains); the profile that does not
+    // fit the LDS slots (more than ~8000 rows) takes an out-of-line copy of the same code on the global pointer
+    if (use_lds) peaks_search<G>(sp, len, inverse, window, two, rng, lg == 0 ? &out[i] : nullptr);
+    else peaks_search_global<G>(g, len, inverse, window, two, rng, lg == 0 ? &out[i] : nullptr);
 }
 
 // LDS plan: `lstride` float64 slots per profile.  Prefer 16 lanes per profile (4 per wave) with as many waves per block as

@@ -14,9 +14,11 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define LFA_HD __host__ __device__ inline
+#define LFA_HD __host__ __device__ __forceinline__
+#define LFA_HD_NOINLINE __host__ __device__ __noinline__
 #else
 #define LFA_HD inline
+#define LFA_HD_NOINLINE inline
 #endif
 
 namespace lfa {
@@ -47,9 +49,10 @@ LFA_HD double np_pairwise_leaf(const F& f, int off, int n) {       // n <= 128
 
 // The recursion of numpy's pairwise sum (split at n/2 rounded down to a multiple of 8 until a piece has <= 128
 // elements) written with an explicit stack, so that the device code has no recursive call (no scratch stack frames).
+// The big-n part is rare (profiles, windows and peaks are short) and kept out of line on the device, so that its stack
+// arrays and registers do not weigh on the kernels that inline np_pairwise.
 template <class F>
-LFA_HD double np_pairwise(const F& f, int off, int n) {
-    if (n <= 128) return np_pairwise_leaf(f, off, n);
+LFA_HD_NOINLINE double np_pairwise_big(const F& f, int off, int n) {
     int f_off[28], f_n[28], f_stage[28];
     double f_left[28];
     int sp = 0;
@@ -72,6 +75,12 @@ LFA_HD double np_pairwise(const F& f, int off, int n) {
         }
     }
     return ret;
+}
+
+template <class F>
+LFA_HD double np_pairwise(const F& f, int off, int n) {
+    if (n <= 128) return np_pairwise_leaf(f, off, n);
+    return np_pairwise_big(f, off, n);
 }
 
 struct ArrAt {
@@ -134,19 +143,31 @@ LFA_HD int np_argext(const double* p, int n, bool want_min) {
 
 struct Peak { int start, end; double area; };
 
+// The two walks from the extremum to the feet of the peak (detection.py:291-300).  dir = -1: the largest s <= from with
+// s == 0 or !(p[s] OP p[s-1] || p[s] CMP thr); dir = +1: the smallest e >= from with e == n-1 or !(p[e] OP p[e+1] || p[e] CMP thr)
+// (OP, CMP = >=, > for peaks; <=, < for valleys).
+LFA_HD bool walk_goes_on(const double* p, int n, int i, int dir, double thr, bool inverse) {
+    if (dir < 0 ? (i <= 0) : (i >= n - 1)) return false;
+    const double a = p[i], b = p[i + dir];
+    return inverse ? (a <= b || a < thr) : (a >= b || a > thr);
+}
+
+struct SeqWalk {
+    LFA_HD int operator()(const double* p, int n, int from, int dir, double thr, bool inverse) const {
+        int i = from;
+        while (walk_goes_on(p, n, i, dir, thr, inverse)) i += dir;
+        return i;
+    }
+};
+
 // detection.py:285-316 given the extremum index (detection.py:284)
-LFA_HD Peak analyze_peaks_at(const double* p, int n, int peak, bool inverse, int window) {
+template <class WK>
+LFA_HD Peak analyze_peaks_at_t(const double* p, int n, int peak, bool inverse, int window, const WK& walk) {
     int ws = peak - window; if (ws < 0) ws = 0;
     int we = peak + window + 1; if (we > n) we = n;
     const double thr = np_pairwise(ArrAt{p}, ws, we - ws) / (double)(we - ws);
-    int s = peak, e = peak;
-    if (inverse) {
-        while (s > 0 && (p[s] <= p[s - 1] || p[s] < thr)) --s;
-        while (e < n - 1 && (p[e] <= p[e + 1] || p[e] < thr)) ++e;
-    } else {
-        while (s > 0 && (p[s] >= p[s - 1] || p[s] > thr)) --s;
-        while (e < n - 1 && (p[e] >= p[e + 1] || p[e] > thr)) ++e;
-    }
+    const int s = walk(p, n, peak, -1, thr, inverse);
+    const int e = walk(p, n, peak, +1, thr, inverse);
     const int m = e - s + 1;
     const double seg = np_pairwise(TrapzAt{p + s}, 0, m - 1);
     const double base = np_pairwise(TrapzLin{Linspace(p[s], p[e], m)}, 0, m - 1);
@@ -154,6 +175,10 @@ LFA_HD Peak analyze_peaks_at(const double* p, int n, int peak, bool inverse, int
     r.start = s; r.end = e;
     r.area = inverse ? (base - seg) : (seg - base);
     return r;
+}
+
+LFA_HD Peak analyze_peaks_at(const double* p, int n, int peak, bool inverse, int window) {
+    return analyze_peaks_at_t(p, n, peak, inverse, window, SeqWalk());
 }
 
 struct SeqArgExt {
@@ -176,12 +201,13 @@ struct TwoPeaks { int n; Peak pk[2]; };
 // detection.py:221-245 (fallback = true, image_analysis) and :257-281 (fallback = false, inverse_image_analysis).
 // `argext(p, n, want_min)` is np.argmax / np.argmin; on the device it is a wave-cooperative search and every lane of
 // the wave runs this function with identical arguments.
-template <class AE>
-LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool fallback, int window, const AE& argext) {
+template <class AE, class WK>
+LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool fallback, int window, const AE& argext,
+                            const WK& walk) {
     TwoPeaks out;
     out.n = 0;
     if (n <= 0) return out;
-    const Peak a = analyze_peaks_at(p, n, argext(p, n, inverse), inverse, window);
+    const Peak a = analyze_peaks_at_t(p, n, argext(p, n, inverse), inverse, window, walk);
     out.n = 1; out.pk[0] = a; out.pk[1] = a;
     const int s = a.start, e = a.end;
     if (!(s > 1 && e < n - 2)) return out;
@@ -201,11 +227,9 @@ LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool 
     const int il = argext(p, left_len, inverse);
     const int ir = argext(right, right_len, inverse);
     const bool take_left = inverse ? (right[ir] > p[il]) : (right[ir] < p[il]);
-    Peak b;
-    if (take_left) {
-        b = analyze_peaks_at(p, left_len, il, inverse, window);
-    } else {
-        b = analyze_peaks_at(right, right_len, ir, inverse, window);
+    // one call site for both sides (the function is inlined on the device: every call site is a full copy)
+    Peak b = analyze_peaks_at_t(take_left ? p : right, take_left ? left_len : right_len, take_left ? il : ir, inverse, window, walk);
+    if (!take_left) {
         b.start += e + rng;
         b.end += e + rng;
     }
@@ -216,7 +240,7 @@ LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool 
 }
 
 LFA_HD TwoPeaks two_peaks(const double* p, int n, bool inverse, int rng, bool fallback, int window) {
-    return two_peaks_t(p, n, inverse, rng, fallback, window, SeqArgExt());
+    return two_peaks_t(p, n, inverse, rng, fallback, window, SeqArgExt(), SeqWalk());
 }
 
 // ---------------------------------------------------------------------------------------------------------------
