@@ -245,17 +245,47 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
     if (bad && lg == 0) store_bad(&peaks[ri], len);               // k_peaks skips ROIs it finds bad by the same test
 }
 
+// numpy's pairwise sum (lfa_algo.h np_pairwise) with the eight running sums of a leaf spread over eight lanes: lane j adds
+// the terms j, j+8, j+16, ... in that order -- exactly the chain numpy's r[j] follows -- then the eight partial sums are
+// exchanged and combined as numpy combines them.
+template <int G>
+struct GroupLeaf {                                               // a piece of at most 128 terms
+    template <class F>
+    __device__ __forceinline__ double operator()(const F& f, int off, int n) const {
+        if (n < 8) return np_pairwise_leaf(f, off, n);
+        const int j = threadIdx.x & 7;
+        const int lim = n - (n % 8);
+        double r = f(off + j);
+        for (int i = 8 + j; i < lim; i += 8) r = r + f(off + i);
+        const int g0 = (threadIdx.x & 63) & ~(G - 1);            // first lane of this group in the wave
+        const double r0 = __shfl(r, g0 + 0), r1 = __shfl(r, g0 + 1), r2 = __shfl(r, g0 + 2), r3 = __shfl(r, g0 + 3);
+        const double r4 = __shfl(r, g0 + 4), r5 = __shfl(r, g0 + 5), r6 = __shfl(r, g0 + 6), r7 = __shfl(r, g0 + 7);
+        double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (int i = lim; i < n; ++i) res = res + f(off + i);
+        return res;
+    }
+};
+
+template <int G>
+struct GroupSum {
+    template <class F>
+    __device__ __forceinline__ double operator()(const F& f, int off, int n) const {
+        if (n <= 128) return GroupLeaf<G>()(f, off, n);
+        return np_pairwise_big(f, off, n, GroupLeaf<G>());         // out of line; splits like numpy, leaves as above
+    }
+};
+
 // the peak search of one profile, run by the G lanes of its group with identical arguments; `dst` non-null on one lane
 template <int G>
 __device__ __forceinline__ void peaks_search(const double* p, int len, int inverse, int window, int two, int rng, LfaPeaks* dst) {
     TwoPeaks tp;
     if (two) {
-        tp = two_peaks_t(p, len, inverse != 0, rng, inverse == 0, window, GroupArgExt<G>(), GroupWalk<G>());
+        tp = two_peaks_t(p, len, inverse != 0, rng, inverse == 0, window, GroupArgExt<G>(), GroupWalk<G>(), GroupSum<G>());
     } else {
         tp.n = 0;
         if (len > 0) {
             const int pk = GroupArgExt<G>()(p, len, inverse != 0);
-            tp.n = 1; tp.pk[0] = analyze_peaks_at_t(p, len, pk, inverse != 0, window, GroupWalk<G>()); tp.pk[1] = tp.pk[0];
+            tp.n = 1; tp.pk[0] = analyze_peaks_at_t(p, len, pk, inverse != 0, window, GroupWalk<G>(), GroupSum<G>()); tp.pk[1] = tp.pk[0];
         }
     }
     if (dst) store_peaks(dst, tp, len);

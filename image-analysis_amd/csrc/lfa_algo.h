@@ -51,8 +51,13 @@ LFA_HD double np_pairwise_leaf(const F& f, int off, int n) {       // n <= 128
 // elements) written with an explicit stack, so that the device code has no recursive call (no scratch stack frames).
 // The big-n part is rare (profiles, windows and peaks are short) and kept out of line on the device, so that its stack
 // arrays and registers do not weigh on the kernels that inline np_pairwise.
-template <class F>
-LFA_HD_NOINLINE double np_pairwise_big(const F& f, int off, int n) {
+struct SeqLeaf {
+    template <class F>
+    LFA_HD double operator()(const F& f, int off, int n) const { return np_pairwise_leaf(f, off, n); }
+};
+
+template <class F, class LEAF>
+LFA_HD_NOINLINE double np_pairwise_big(const F& f, int off, int n, const LEAF& leaf) {
     int f_off[28], f_n[28], f_stage[28];
     double f_left[28];
     int sp = 0;
@@ -60,7 +65,7 @@ LFA_HD_NOINLINE double np_pairwise_big(const F& f, int off, int n) {
     double ret = 0.0;
     while (sp >= 0) {
         const int cn = f_n[sp], co = f_off[sp];
-        if (cn <= 128) { ret = np_pairwise_leaf(f, co, cn); --sp; continue; }
+        if (cn <= 128) { ret = leaf(f, co, cn); --sp; continue; }
         int n2 = cn / 2;
         n2 -= n2 % 8;
         if (f_stage[sp] == 0) {
@@ -80,7 +85,7 @@ LFA_HD_NOINLINE double np_pairwise_big(const F& f, int off, int n) {
 template <class F>
 LFA_HD double np_pairwise(const F& f, int off, int n) {
     if (n <= 128) return np_pairwise_leaf(f, off, n);
-    return np_pairwise_big(f, off, n);
+    return np_pairwise_big(f, off, n, SeqLeaf());
 }
 
 struct ArrAt {
@@ -161,16 +166,23 @@ struct SeqWalk {
 };
 
 // detection.py:285-316 given the extremum index (detection.py:284)
-template <class WK>
-LFA_HD Peak analyze_peaks_at_t(const double* p, int n, int peak, bool inverse, int window, const WK& walk) {
+struct SeqSum {
+    template <class F>
+    LFA_HD double operator()(const F& f, int off, int n) const { return np_pairwise(f, off, n); }
+};
+
+// `walk` and `sum` are policies: sequential on the host (SeqWalk, SeqSum), cooperative over the lanes of a group on the
+// device (k_profile.hip GroupWalk, GroupSum) -- same values, same rounding order.
+template <class WK, class SM>
+LFA_HD Peak analyze_peaks_at_t(const double* p, int n, int peak, bool inverse, int window, const WK& walk, const SM& sum) {
     int ws = peak - window; if (ws < 0) ws = 0;
     int we = peak + window + 1; if (we > n) we = n;
-    const double thr = np_pairwise(ArrAt{p}, ws, we - ws) / (double)(we - ws);
+    const double thr = sum(ArrAt{p}, ws, we - ws) / (double)(we - ws);
     const int s = walk(p, n, peak, -1, thr, inverse);
     const int e = walk(p, n, peak, +1, thr, inverse);
     const int m = e - s + 1;
-    const double seg = np_pairwise(TrapzAt{p + s}, 0, m - 1);
-    const double base = np_pairwise(TrapzLin{Linspace(p[s], p[e], m)}, 0, m - 1);
+    const double seg = sum(TrapzAt{p + s}, 0, m - 1);
+    const double base = sum(TrapzLin{Linspace(p[s], p[e], m)}, 0, m - 1);
     Peak r;
     r.start = s; r.end = e;
     r.area = inverse ? (base - seg) : (seg - base);
@@ -178,7 +190,7 @@ LFA_HD Peak analyze_peaks_at_t(const double* p, int n, int peak, bool inverse, i
 }
 
 LFA_HD Peak analyze_peaks_at(const double* p, int n, int peak, bool inverse, int window) {
-    return analyze_peaks_at_t(p, n, peak, inverse, window, SeqWalk());
+    return analyze_peaks_at_t(p, n, peak, inverse, window, SeqWalk(), SeqSum());
 }
 
 struct SeqArgExt {
@@ -201,13 +213,13 @@ struct TwoPeaks { int n; Peak pk[2]; };
 // detection.py:221-245 (fallback = true, image_analysis) and :257-281 (fallback = false, inverse_image_analysis).
 // `argext(p, n, want_min)` is np.argmax / np.argmin; on the device it is a wave-cooperative search and every lane of
 // the wave runs this function with identical arguments.
-template <class AE, class WK>
+template <class AE, class WK, class SM>
 LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool fallback, int window, const AE& argext,
-                            const WK& walk) {
+                            const WK& walk, const SM& sum) {
     TwoPeaks out;
     out.n = 0;
     if (n <= 0) return out;
-    const Peak a = analyze_peaks_at_t(p, n, argext(p, n, inverse), inverse, window, walk);
+    const Peak a = analyze_peaks_at_t(p, n, argext(p, n, inverse), inverse, window, walk, sum);
     out.n = 1; out.pk[0] = a; out.pk[1] = a;
     const int s = a.start, e = a.end;
     if (!(s > 1 && e < n - 2)) return out;
@@ -228,7 +240,7 @@ LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool 
     const int ir = argext(right, right_len, inverse);
     const bool take_left = inverse ? (right[ir] > p[il]) : (right[ir] < p[il]);
     // one call site for both sides (the function is inlined on the device: every call site is a full copy)
-    Peak b = analyze_peaks_at_t(take_left ? p : right, take_left ? left_len : right_len, take_left ? il : ir, inverse, window, walk);
+    Peak b = analyze_peaks_at_t(take_left ? p : right, take_left ? left_len : right_len, take_left ? il : ir, inverse, window, walk, sum);
     if (!take_left) {
         b.start += e + rng;
         b.end += e + rng;
@@ -240,7 +252,7 @@ LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool 
 }
 
 LFA_HD TwoPeaks two_peaks(const double* p, int n, bool inverse, int rng, bool fallback, int window) {
-    return two_peaks_t(p, n, inverse, rng, fallback, window, SeqArgExt(), SeqWalk());
+    return two_peaks_t(p, n, inverse, rng, fallback, window, SeqArgExt(), SeqWalk(), SeqSum());
 }
 
 // ---------------------------------------------------------------------------------------------------------------
