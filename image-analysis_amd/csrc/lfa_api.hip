@@ -31,6 +31,20 @@ int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(LFA_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));          \
     } while (0)
 
+// makes `device` current for the duration of a call and puts the caller's device back afterwards
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device); else if (err == hipSuccess) prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define LFA_ON_DEVICE(dev)                                                                               \
+    DeviceGuard guard_(dev);                                                                            \
+    if (guard_.err != hipSuccess) return fail(LFA_ERR_HIP, "selecting device %d: %s", (dev), hipGetErrorString(guard_.err))
+
 struct Buf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -219,7 +233,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (min_maxr < 0 || min_maxc < 0) return fail(LFA_ERR_ARG, "min_maxr/min_maxc must be >= 0");
     if (!out_strips || !out_counts) return fail(LFA_ERR_ARG, "null output pointer");
     if (max_strips < 1 || max_strips > 1024) return fail(LFA_ERR_ARG, "max_strips must be in [1,1024]");
-    LFA_HIP(hipSetDevice(h->device));
+    LFA_ON_DEVICE(h->device);
     if ((rc = ensure_workspace(h, n, H, W, C, dtype, L, max_strips))) return rc;
     lfa::Job j = make_job(h, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
     lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
@@ -249,7 +263,7 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
     int ndev = 0;
     LFA_HIP(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(LFA_ERR_ARG, "device %d not in [0,%d)", device, ndev);
-    LFA_HIP(hipSetDevice(device));
+    LFA_ON_DEVICE(device);
     LfaContext* h = new (std::nothrow) LfaContext();
     if (!h) return fail(LFA_ERR_NOMEM, "out of host memory");
     h->device = device; h->max_h = max_h; h->max_w = max_w; h->max_c = max_c; h->max_batch = max_batch;
@@ -277,7 +291,7 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
 
 int lfa_destroy(LfaHandle h) {
     if (!h) return LFA_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard_(h->device);
     for (Buf* b : h->all()) if (b->p) (void)hipFree(b->p);
     delete h->timer;
     delete h;
@@ -286,7 +300,7 @@ int lfa_destroy(LfaHandle h) {
 
 int lfa_set_gamma_lut(LfaHandle h, int dtype, const void* lut, int n) {
     if (!h || !lut) return fail(LFA_ERR_ARG, "null argument");
-    LFA_HIP(hipSetDevice(h->device));
+    LFA_ON_DEVICE(h->device);
     if (dtype == LFA_U8) {
         if (n != 256) return fail(LFA_ERR_ARG, "uint8 table needs 256 entries, got %d", n);
         const uint8_t* t = (const uint8_t*)lut;
@@ -333,7 +347,7 @@ static int profile_impl(LfaHandle h, const void* images, int dtype, int n, int H
     if (n_rois == 0) return LFA_OK;
     if (!rois || !out_profiles || !out_peaks) return fail(LFA_ERR_ARG, "null pointer");
     if (profile_stride < 1) return fail(LFA_ERR_ARG, "profile_stride must be >= 1");
-    LFA_HIP(hipSetDevice(h->device));
+    LFA_ON_DEVICE(h->device);
     lfa::Job j{};
     j.images = (const uint8_t*)images;
     j.img_bytes = (int64_t)H * W * C * (dtype == LFA_U16 ? 2 : 1);
@@ -367,7 +381,7 @@ int lfa_peaks_batch(LfaHandle h, const double* profiles, const int32_t* lengths,
     if (n_profiles == 0) return LFA_OK;
     if (!profiles || !lengths || !out_peaks) return fail(LFA_ERR_ARG, "null pointer");
     if (profile_stride < 1 || window_size < 0) return fail(LFA_ERR_ARG, "bad stride / window");
-    LFA_HIP(hipSetDevice(h->device));
+    LFA_ON_DEVICE(h->device);
     TimerScope ts(h);
     LFA_HIP(lfa::launch_peaks(profiles, lengths, n_profiles, profile_stride, inverse, window_size, two_peaks, range,
                               out_peaks, (hipStream_t)stream));
@@ -384,7 +398,7 @@ int lfa_analyze_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
     int rc = check_images(h, images, dtype, n, H, W, C);
     if (rc) return rc;
     if (max_strips < 1 || max_strips > 1024) return fail(LFA_ERR_ARG, "max_strips must be in [1,1024]");
-    LFA_HIP(hipSetDevice(h->device));
+    LFA_ON_DEVICE(h->device);
     if (!out_rois) {
         if ((rc = ensure(h->rois, (size_t)n * max_strips * sizeof(LfaRoi)))) return rc;
         out_rois = (LfaRoi*)h->rois.p;
@@ -420,7 +434,7 @@ int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H,
         for (int k = 0; k < 2 * radius + 1; ++k) sum += w[k];
         for (int k = 0; k < 2 * radius + 1; ++k) w[k] /= sum;
     }
-    LFA_HIP(hipSetDevice(h->device));
+    LFA_ON_DEVICE(h->device);
     lfa::Job j{};
     j.images = (const uint8_t*)images;
     j.img_bytes = (int64_t)H * W * C * (dtype == LFA_U16 ? 2 : 1);
@@ -434,7 +448,7 @@ int lfa_debug_fetch(LfaHandle h, int image_index, int what, void* out, int64_t o
     if (!h || !out) return fail(LFA_ERR_ARG, "null argument");
     if (!h->have_last) return fail(LFA_ERR_ARG, "no detect/analyze call has run on this handle yet");
     if (image_index < 0 || image_index >= h->last.n) return fail(LFA_ERR_ARG, "image_index %d outside the last batch of %d", image_index, h->last.n);
-    LFA_HIP(hipSetDevice(h->device));
+    LFA_ON_DEVICE(h->device);
     hipError_t e = lfa::launch_debug(h->last, image_index, what, out, out_bytes, (hipStream_t)stream);
     if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? LFA_ERR_ARG : LFA_ERR_HIP, "lfa_debug_fetch(what=%d): %s", what, hipGetErrorString(e));
     return LFA_OK;
@@ -442,7 +456,7 @@ int lfa_debug_fetch(LfaHandle h, int image_index, int what, void* out, int64_t o
 
 int lfa_timing_enable(LfaHandle h, const char* kernel_filter) {
     if (!h) return fail(LFA_ERR_ARG, "null handle");
-    LFA_HIP(hipSetDevice(h->device));
+    LFA_ON_DEVICE(h->device);
     if (!kernel_filter || !*kernel_filter) {
         if (h->timer) { LFA_HIP(hipDeviceSynchronize()); delete h->timer; h->timer = nullptr; }
         return LFA_OK;
@@ -457,7 +471,7 @@ int lfa_timing_read(LfaHandle h, int max_entries, char* names, double* total_ms,
     if (!h || !names || !total_ms || !launches || !n_out) return fail(LFA_ERR_ARG, "null argument");
     *n_out = 0;
     if (!h->timer) return LFA_OK;
-    LFA_HIP(hipSetDevice(h->device));
+    LFA_ON_DEVICE(h->device);
     LFA_HIP(hipDeviceSynchronize());
     EventTimer* t = h->timer;
     int n = 0;
@@ -482,7 +496,7 @@ int lfa_timing_read(LfaHandle h, int max_entries, char* names, double* total_ms,
 
 int lfa_sync(LfaHandle h, void* stream) {
     if (!h) return fail(LFA_ERR_ARG, "null handle");
-    LFA_HIP(hipSetDevice(h->device));
+    LFA_ON_DEVICE(h->device);
     LFA_HIP(hipStreamSynchronize((hipStream_t)stream));
     return LFA_OK;
 }

@@ -14,6 +14,7 @@
  *     image i starts at byte i * H*W*C*sizeof(pixel);
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls enqueue work and
  *     return without waiting unless documented otherwise; one handle per device and per host thread;
+ *     a call makes the handle's device current while it runs and leaves the caller's current device as it found it;
  *   - nothing here reads or writes host memory behind the caller's back except the documented
  *     host-pointer parameters.
  */
