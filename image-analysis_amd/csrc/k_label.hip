@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_union(Job j) {
     }
 }
 
-// after k_union: point every run at its root, fold area / bbox into the root, flag the root's first pixel.
+// after k_union: point every run at its root, fold area / bbox into the root, list the roots and count them per row.
 // Runs of one component sit next to each other in the run list (adjacent columns), so the lanes of a wave mostly share
 // a root: they are combined with wave reductions and ONE lane issues the atomics (otherwise every run of a strip
 // would queue five atomics on the same five words).
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_flatten(Job j) {
     const int64_t rbase = (int64_t)img * j.run_cap;
     const int nr = min((int)off[j.W], j.run_cap);
     int* parent = j.parent + rbase;
-    uint64_t* fb = j.firstbits + (int64_t)img * j.nwp;
+    uint32_t* rowcnt = j.rowcnt + (int64_t)img * (j.H + 1);
     const int lane = threadIdx.x & 63;
     for (int i0 = blockIdx.x * blockDim.x; i0 < nr; i0 += gridDim.x * blockDim.x) {
         const int i = i0 + threadIdx.x;
@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256) void k_flatten(Job j) {
             const uint32_t se = j.run_se[rbase + i];
             s = (int)(se & 0xffffu); e = (int)(se >> 16); c = j.run_col[rbase + i];
             if (r != i) __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else atomicOr((unsigned long long*)&fb[(int64_t)s * j.W64 + (c >> 6)], 1ull << (c & 63));
+            else {                                                   // a root: its run starts at the component's raster-first pixel
+                atomicAdd(&rowcnt[s], 1u);
+                j.rootlist[rbase + atomicAdd(&rowcnt[j.H], 1u)] = i;
+            }
         }
         const bool need = active && r != i;
         unsigned long long todo = __ballot(need);
@@ -198,74 +201,66 @@ __global__ __launch_bounds__(256) void k_flatten(Job j) {
     }
 }
 
-// exclusive prefix popcount over the first-pixel bitmap of one image -> rank of every component in raster order.
-// One 1024-thread block per image; a tile is 4096 words (4 consecutive words per thread, 32-byte loads); tiles without
-// any set bit (almost all) skip the block scan.
-__global__ __launch_bounds__(1024) void k_rank_scan(Job j) {
+// Label ids: scipy.ndimage.label numbers the components in raster order of their first pixel, i.e. label = 1 + rank of
+// the root run's (row, col) among all roots.  Roots are few (tens to a few thousand) next to H*W pixels, so they are
+// ranked as a list: counted per row by k_flatten, rows prefix-summed here, roots dropped into their row's bucket, and
+// each root's rank = roots in earlier rows + roots of its own row further left.  One 1024-thread block per image.
+__global__ __launch_bounds__(1024) void k_rank_roots(Job j) {
     const int img = blockIdx.x;
-    const int64_t nwp = j.nwp;
-    const uint64_t* fb = j.firstbits + (int64_t)img * nwp;
-    uint32_t* wr = j.wordrank + (int64_t)img * nwp;
-    __shared__ uint32_t wsum[16];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t carry = 0;
-    for (int64_t base = 0; base < nwp; base += 4096) {
-        const int64_t k = base + 4 * t;
-        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-        if (k < nwp) {
-            const uint4 a = *(const uint4*)(fb + k), b = *(const uint4*)(fb + k + 2);
-            p0 = __popc(a.x) + __popc(a.y); p1 = __popc(a.z) + __popc(a.w);
-            p2 = __popc(b.x) + __popc(b.y); p3 = __popc(b.z) + __popc(b.w);
-        }
-        const uint32_t sum = p0 + p1 + p2 + p3;
-        const int any = __syncthreads_or(sum != 0);
-        uint32_t excl = 0, tot = 0;
-        if (any) {
-            uint32_t inc = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
-            if (lane == 63) wsum[wv] = inc;
-            __syncthreads();
-            uint32_t woff = 0;
-            for (int q = 0; q < 16; ++q) { const uint32_t v = wsum[q]; tot += v; woff += (q < wv) ? v : 0u; }
-            excl = woff + inc - sum;
-            __syncthreads();
-        }
-        if (k < nwp) {
-            uint4 o;
-            o.x = carry + excl; o.y = o.x + p0; o.z = o.y + p1; o.w = o.z + p2;
-            *(uint4*)(wr + k) = o;
-        }
-        carry += tot;
-    }
-    if (t == 0) {
-        j.info[img].n_labels = (int)carry;
-        j.info[img].label00 = (int)(fb[0] & 1ull);          // pixel (0,0) foreground <=> it is the first pixel of label 1
-    }
-}
-
-__device__ inline int label_of_root(const Job& j, int img, int s, int c) {
-    const int64_t wi = (int64_t)img * j.nwp + (int64_t)s * j.W64 + (c >> 6);
-    const uint64_t w = j.firstbits[wi];
-    return (int)(j.wordrank[wi] + __popcll(w & ((1ull << (c & 63)) - 1ull))) + 1;
-}
-
-__global__ __launch_bounds__(256) void k_label_roots(Job j) {
-    const int img = blockIdx.y;
-    const uint32_t* off = j.col_cnt + (int64_t)img * (j.W + 1);
+    const int H = j.H;
+    uint32_t* rowcnt = j.rowcnt + (int64_t)img * (H + 1);
+    uint32_t* rowpos = j.rowpos + (int64_t)img * (H + 1);
     const int64_t rbase = (int64_t)img * j.run_cap;
-    const int nr = min((int)off[j.W], j.run_cap);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) {
-        if (j.parent[rbase + i] != i) continue;
-        const uint32_t se = j.run_se[rbase + i];
-        const int lab = label_of_root(j, img, (int)(se & 0xffffu), j.run_col[rbase + i]);
-        j.root_of_label[rbase + lab - 1] = i;
+    const int K = min((int)rowcnt[H], j.run_cap);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    __shared__ uint32_t wsum[16];
+    __shared__ int s_label00;
+    if (t == 0) s_label00 = 0;
+    // exclusive prefix over the rows: a contiguous segment of rows per thread, block scan of the segment sums
+    const int seg = (H + 1023) / 1024;
+    const int r0 = min(H, t * seg), r1 = min(H, r0 + seg);
+    uint32_t sum = 0;
+    for (int r = r0; r < r1; ++r) sum += rowcnt[r];
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int q = 0; q < wv; ++q) run += wsum[q];
+    for (int r = r0; r < r1; ++r) { const uint32_t c = rowcnt[r]; rowcnt[r] = run; rowpos[r] = run; run += c; }   // rowcnt becomes the offsets
+    __threadfence_block();
+    __syncthreads();
+    // roots into the buckets of their rows
+    for (int q = t; q < K; q += 1024) {
+        const int i = j.rootlist[rbase + q];
+        const int s = (int)(j.run_se[rbase + i] & 0xffffu);
+        j.bucket[rbase + atomicAdd(&rowpos[s], 1u)] = i;
     }
+    __threadfence_block();
+    __syncthreads();
+    for (int q = t; q < K; q += 1024) {
+        const int i = j.rootlist[rbase + q];
+        const int s = (int)(j.run_se[rbase + i] & 0xffffu), c = j.run_col[rbase + i];
+        const uint32_t lo = __hip_atomic_load(&rowcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t hi = __hip_atomic_load(&rowpos[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t before = 0;
+        for (uint32_t b = lo; b < hi; ++b) {
+            const int o = __hip_atomic_load(&j.bucket[rbase + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            before += (j.run_col[rbase + o] < c) ? 1u : 0u;
+        }
+        const int lab = (int)(lo + before) + 1;
+        j.root_of_label[rbase + lab - 1] = i;
+        j.label_of_run[rbase + i] = lab;
+        if (s == 0 && c == 0) s_label00 = 1;                // pixel (0,0) is foreground <=> it is the first pixel of label 1
+    }
+    __syncthreads();
+    if (t == 0) { j.info[img].n_labels = K; j.info[img].label00 = s_label00; }
 }
 
 hipError_t launch_label(const Job& j, hipStream_t s) {
     const dim3 gcol((j.W + 255) / 256, j.n);
-    hipError_t e = hipMemsetAsync(j.firstbits, 0, (size_t)j.n * j.nwp * sizeof(uint64_t), s);
+    hipError_t e = hipMemsetAsync(j.rowcnt, 0, (size_t)j.n * (j.H + 1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     LFA_LAUNCH("k_runs_count", k_runs_count, gcol, dim3(256), 0, s, j);
     LFA_LAUNCH("k_col_scan", k_col_scan, dim3(j.n), dim3(256), 0, s, j);
@@ -276,8 +271,7 @@ hipError_t launch_label(const Job& j, hipStream_t s) {
     const dim3 grun(gx, j.n);
     LFA_LAUNCH("k_union", k_union, grun, dim3(256), 0, s, j);
     LFA_LAUNCH("k_flatten", k_flatten, grun, dim3(256), 0, s, j);
-    LFA_LAUNCH("k_rank_scan", k_rank_scan, dim3(j.n), dim3(1024), 0, s, j);
-    LFA_LAUNCH("k_label_roots", k_label_roots, grun, dim3(256), 0, s, j);
+    LFA_LAUNCH("k_rank_roots", k_rank_roots, dim3(j.n), dim3(1024), 0, s, j);
     return hipGetLastError();
 }
 
@@ -301,8 +295,7 @@ __global__ void k_dbg_paint(Job j, int img, int what, void* out) {
             for (int r = s; r <= e; ++r) ((uint8_t*)out)[(int64_t)r * j.W + c] = 1;
         } else {
             const int root = j.parent[rbase + i];
-            const uint32_t rse = j.run_se[rbase + root];
-            const int lab = label_of_root(j, img, (int)(rse & 0xffffu), j.run_col[rbase + root]);
+            const int lab = j.label_of_run[rbase + root];
             for (int r = s; r <= e; ++r) ((int32_t*)out)[(int64_t)r * j.W + c] = lab;
         }
     }

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
             if (t == 64) otsu_seq_bwd(cb, lb, rn, sb, w2 + r0, s2 + r0);
             __syncthreads();
         }
-        __threadfence();
+        __threadfence_block();
         __syncthreads();
         for (int b = b0; b < b1; ++b)
             if (b < nb - 1 && lut(xmin + b + 1) != lut(xmin + b)) {

@@ -92,13 +92,13 @@ struct LfaContext {
     int max_h = 0, max_w = 0, max_c = 0, max_batch = 0;
     int gray_variant = LFA_GRAY_FMA_102;
     int debug_flags = 0;
-    Buf info, hist, otsu_w, otsu_s, edges, edges_i, bins, maskT, col_cnt, run_se, run_col, parent, area, bbox, firstbits, wordrank, root_of_label, cand,
+    Buf info, hist, otsu_w, otsu_s, edges, edges_i, bins, maskT, col_cnt, run_se, run_col, parent, area, bbox, rowcnt, rowpos, rootlist, bucket, label_of_run, root_of_label, cand,
         cand_sum, cand_rs_off, rowsum, slot_rs_off, lut8, lut16, rois;
     lfa::Job last{};
     bool have_last = false;
     EventTimer* timer = nullptr;
     std::vector<Buf*> all() {
-        return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &firstbits, &wordrank,
+        return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
                 &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &lut8, &lut16, &rois};
     }
 };
@@ -131,7 +131,7 @@ int run_capacity(int H, int W, int L) {
 // size every buffer for (n images of H x W, line_length L, dtype); grows only
 int ensure_workspace(LfaContext* h, int n, int H, int W, int C, int dtype, int L, int max_strips) {
     const size_t N = (size_t)n;
-    const int HB = (H + 63) / 64, W64 = (W + 63) / 64;
+    const int HB = (H + 63) / 64;
     const size_t cap = (size_t)run_capacity(H, W, L);
     const size_t hist_stride = (dtype == LFA_U16) ? lfa::kHistBinsU16 : 256;
     int rc;
@@ -151,9 +151,11 @@ int ensure_workspace(LfaContext* h, int n, int H, int W, int C, int dtype, int L
     if ((rc = ensure(h->parent, N * cap * 4))) return rc;
     if ((rc = ensure(h->area, N * cap * 4))) return rc;
     if ((rc = ensure(h->bbox, N * cap * 16))) return rc;
-    const size_t nwp = ((size_t)H * W64 + 3) & ~(size_t)3;
-    if ((rc = ensure(h->firstbits, N * nwp * 8))) return rc;
-    if ((rc = ensure(h->wordrank, N * nwp * 4))) return rc;
+    if ((rc = ensure(h->rowcnt, N * ((size_t)H + 1) * 4))) return rc;
+    if ((rc = ensure(h->rowpos, N * ((size_t)H + 1) * 4))) return rc;
+    if ((rc = ensure(h->rootlist, N * cap * 4))) return rc;
+    if ((rc = ensure(h->bucket, N * cap * 4))) return rc;
+    if ((rc = ensure(h->label_of_run, N * cap * 4))) return rc;
     if ((rc = ensure(h->root_of_label, N * cap * 4))) return rc;
     const size_t ccap = (size_t)H * W / lfa::kAreaMin + 1;
     if ((rc = ensure(h->cand, N * ccap * 4))) return rc;
@@ -186,8 +188,7 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.gray_variant = h->gray_variant;
     j.debug_flags = h->debug_flags;
     j.aligned16 = (((uintptr_t)images & 15) == 0 && (j.img_bytes & 15) == 0) ? 1 : 0;
-    j.HB = (H + 63) / 64; j.W64 = (W + 63) / 64;
-    j.nwp = ((int64_t)H * j.W64 + 3) & ~(int64_t)3;
+    j.HB = (H + 63) / 64;
     j.run_cap = run_capacity(H, W, L);
     j.max_strips = max_strips;
     j.info = (LfaImageInfo*)h->info.p;
@@ -206,8 +207,11 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.parent = (int32_t*)h->parent.p;
     j.area = (int32_t*)h->area.p;
     j.bbox = (int32_t*)h->bbox.p;
-    j.firstbits = (uint64_t*)h->firstbits.p;
-    j.wordrank = (uint32_t*)h->wordrank.p;
+    j.rowcnt = (uint32_t*)h->rowcnt.p;
+    j.rowpos = (uint32_t*)h->rowpos.p;
+    j.rootlist = (int32_t*)h->rootlist.p;
+    j.bucket = (int32_t*)h->bucket.p;
+    j.label_of_run = (int32_t*)h->label_of_run.p;
     j.root_of_label = (int32_t*)h->root_of_label.p;
     j.cand_cap = (int32_t)((int64_t)H * W / lfa::kAreaMin + 1);
     j.cand = (int32_t*)h->cand.p;

@@ -32,8 +32,6 @@ struct Job {
     int32_t aligned16;       // images base and per-image / per-row strides allow 16-byte vector loads
     // derived
     int32_t HB;              // row blocks of 64 rows
-    int32_t W64;             // 64-column words per row of the first-pixel bitmap
-    int64_t nwp;             // words per image of that bitmap: H*W64 rounded up to a multiple of 4
     int32_t run_cap;         // run capacity per image
     int32_t max_strips;
     // workspace (all per image, image i at i*stride)
@@ -53,8 +51,11 @@ struct Job {
     int32_t* parent;         // [n][run_cap]
     int32_t* area;           // [n][run_cap]    valid at roots
     int32_t* bbox;           // [n][run_cap][4] minr, minc, maxr, maxc (half-open) valid at roots
-    uint64_t* firstbits;     // [n][nwp]        bit set at the raster-first pixel of every component
-    uint32_t* wordrank;      // [n][nwp]        exclusive prefix popcount of firstbits
+    uint32_t* rowcnt;        // [n][H+1]        roots (components) whose first pixel lies in row r; element H = number of roots
+    uint32_t* rowpos;        // [n][H+1]        exclusive prefix of rowcnt, then the fill cursor of every row's bucket
+    int32_t* rootlist;       // [n][run_cap]    the root runs in discovery order
+    int32_t* bucket;         // [n][run_cap]    the same grouped by row of their first pixel
+    int32_t* label_of_run;   // [n][run_cap]    label id, written for root runs only
     int32_t* root_of_label;  // [n][run_cap]
     int32_t cand_cap;        // candidates per image: H*W/100 + 1 (disjoint components of >= 100 pixels)
     int32_t* cand;           // [n][cand_cap]   labels (1-based) with area >= 100, ascending
