@@ -47,12 +47,21 @@ __device__ inline void column_runs(const uint64_t* colw, int HB, int H, int W, i
     if (start >= 0 && run_survives(start, H - 1, H, L)) emit(start, H - 1);
 }
 
+// one thread per column: count the surviving runs and park them in the column's own slots of run_tmp (run_cap is
+// runs_per_col * W, and runs_per_col bounds what a column can hold), so that k_runs_fill compacts the run list
+// without reading the mask a second time
 __global__ __launch_bounds__(256) void k_runs_count(Job j) {
     const int img = blockIdx.y;
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= j.W) return;
     int n = 0;
-    column_runs(j.maskT + (int64_t)img * j.HB * j.W + c, j.HB, j.H, j.W, j.line_length, [&](int, int) { ++n; });
+    uint32_t* tmp = j.run_tmp + (int64_t)img * j.run_cap + (int64_t)c * j.runs_per_col;
+    const int per = j.runs_per_col;
+    column_runs(j.maskT + (int64_t)img * j.HB * j.W + c, j.HB, j.H, j.W, j.line_length, [&](int s, int e) {
+        if (n < per) tmp[n] = (uint32_t)s | ((uint32_t)e << 16);
+        ++n;
+    });
+    if (n > per) { n = per; atomicOr(&j.info[img].status, 2); }          // cannot happen: runs_per_col is an upper bound
     j.col_cnt[(int64_t)img * (j.W + 1) + c] = (uint32_t)n;
 }
 
@@ -85,20 +94,21 @@ __global__ __launch_bounds__(256) void k_runs_fill(Job j) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= j.W) return;
     const int64_t rbase = (int64_t)img * j.run_cap;
-    uint32_t idx = j.col_cnt[(int64_t)img * (j.W + 1) + c];
-    const uint32_t cap = (uint32_t)j.run_cap;
-    column_runs(j.maskT + (int64_t)img * j.HB * j.W + c, j.HB, j.H, j.W, j.line_length, [&](int s, int e) {
-        if (idx < cap) {
-            const int64_t i = rbase + idx;
-            j.run_se[i] = (uint32_t)s | ((uint32_t)e << 16);
-            j.run_col[i] = (uint16_t)c;
-            j.parent[i] = (int)idx;
-            j.area[i] = e - s + 1;
-            int4 bb; bb.x = s; bb.y = c; bb.z = e + 1; bb.w = c + 1;
-            *(int4*)(j.bbox + i * 4) = bb;
-        }
-        ++idx;
-    });
+    const uint32_t* cc = j.col_cnt + (int64_t)img * (j.W + 1);
+    const uint32_t first = cc[c], cap = (uint32_t)j.run_cap;
+    const uint32_t end = min(cc[c + 1], cap);
+    const uint32_t* tmp = j.run_tmp + rbase + (int64_t)c * j.runs_per_col;
+    for (uint32_t idx = first; idx < end; ++idx) {
+        const uint32_t se = tmp[idx - first];
+        const int s = (int)(se & 0xffffu), e = (int)(se >> 16);
+        const int64_t i = rbase + idx;
+        j.run_se[i] = se;
+        j.run_col[i] = (uint16_t)c;
+        j.parent[i] = (int)idx;
+        j.area[i] = e - s + 1;
+        int4 bb; bb.x = s; bb.y = c; bb.z = e + 1; bb.w = c + 1;
+        *(int4*)(j.bbox + i * 4) = bb;
+    }
 }
 
 // ---- union-find on runs ---------------------------------------------------------------------------------------------

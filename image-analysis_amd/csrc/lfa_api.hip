@@ -92,13 +92,13 @@ struct LfaContext {
     int max_h = 0, max_w = 0, max_c = 0, max_batch = 0;
     int gray_variant = LFA_GRAY_FMA_102;
     int debug_flags = 0;
-    Buf info, hist, otsu_w, otsu_s, edges, edges_i, bins, maskT, col_cnt, run_se, run_col, parent, area, bbox, rowcnt, rowpos, rootlist, bucket, label_of_run, root_of_label, cand,
+    Buf info, hist, otsu_w, otsu_s, edges, edges_i, bins, maskT, col_cnt, run_tmp, run_se, run_col, parent, area, bbox, rowcnt, rowpos, rootlist, bucket, label_of_run, root_of_label, cand,
         cand_sum, cand_rs_off, rowsum, slot_rs_off, lut8, lut16, rois;
     lfa::Job last{};
     bool have_last = false;
     EventTimer* timer = nullptr;
     std::vector<Buf*> all() {
-        return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
+        return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_tmp, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
                 &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &lut8, &lut16, &rois};
     }
 };
@@ -146,6 +146,7 @@ int ensure_workspace(LfaContext* h, int n, int H, int W, int C, int dtype, int L
     if (C == 3 && (rc = ensure(h->bins, N * (size_t)H * W))) return rc;
     if ((rc = ensure(h->maskT, N * HB * W * 8))) return rc;
     if ((rc = ensure(h->col_cnt, N * (W + 1) * 4))) return rc;
+    if ((rc = ensure(h->run_tmp, N * cap * 4))) return rc;
     if ((rc = ensure(h->run_se, N * cap * 4))) return rc;
     if ((rc = ensure(h->run_col, N * cap * 2))) return rc;
     if ((rc = ensure(h->parent, N * cap * 4))) return rc;
@@ -202,6 +203,8 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.bins = (C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2)) ? (uint8_t*)h->bins.p : nullptr;
     j.maskT = (uint64_t*)h->maskT.p;
     j.col_cnt = (uint32_t*)h->col_cnt.p;
+    j.run_tmp = (uint32_t*)h->run_tmp.p;
+    j.runs_per_col = j.run_cap / W;
     j.run_se = (uint32_t*)h->run_se.p;
     j.run_col = (uint16_t*)h->run_col.p;
     j.parent = (int32_t*)h->parent.p;

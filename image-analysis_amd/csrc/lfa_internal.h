@@ -46,6 +46,8 @@ struct Job {
                              //           instead of the image (1 byte per pixel instead of 3); null = not used
     uint64_t* maskT;         // [n][HB][W]      vertical 64-row words, thresholded image
     uint32_t* col_cnt;       // [n][W+1]        runs per column -> exclusive offsets
+    uint32_t* run_tmp;       // [n][run_cap]    runs parked per column (runs_per_col slots each) between counting and compaction
+    int32_t runs_per_col;    // run_cap / W
     uint32_t* run_se;        // [n][run_cap]    start | (end_inclusive << 16)
     uint16_t* run_col;       // [n][run_cap]
     int32_t* parent;         // [n][run_cap]
