@@ -128,8 +128,7 @@ __device__ inline int uf_find_live(int* parent, int i) {
     }
 }
 
-__device__ inline void uf_unite(const Job& j, int64_t rbase, int a, int b) {
-    int* parent = j.parent + rbase;
+__device__ inline void uf_unite(const Job& j, int64_t rbase, int* parent, int a, int b) {
     for (;;) {
         a = uf_find_live(parent, a);
         b = uf_find_live(parent, b);
@@ -141,12 +140,39 @@ __device__ inline void uf_unite(const Job& j, int64_t rbase, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_union(Job j) {
-    const int img = blockIdx.y;
+constexpr int kLdsRuns = 16384;      // union-find parents of up to this many runs live in LDS (64 KiB)
+
+// Connected components of one image in ONE 1024-thread block: union-find over the runs, flatten + fold area / bbox into
+// the roots, number the roots.  Images have a few hundred to a few thousand runs (the strips' columns plus noise that
+// survived the opening), so the parent array normally sits in LDS and the CAS chains cost LDS latencies; an image with
+// more than kLdsRuns runs works on the global array through the same code.
+//   union  : runs in adjacent columns whose row ranges, widened by one, overlap are united (8-connectivity)
+//   flatten: every run points at its root; area and bbox are folded into the root with wave-aggregated atomics (runs of
+//            one component sit next to each other in the run list, so the lanes of a wave mostly share a root);
+//            roots are listed and counted per row of their first pixel
+//   rank   : scipy.ndimage.label numbers components in raster order of their first pixel = 1 + rank of the root's
+//            (row, col): rows prefix-summed, roots dropped into their row's bucket, rank = roots in earlier rows + roots
+//            of the same row further left
+__global__ __launch_bounds__(1024) void k_components(Job j) {
+    __shared__ int lds_parent[kLdsRuns];
+    __shared__ uint32_t wsum[16];
+    __shared__ int s_label00;
+    const int img = blockIdx.x;
+    const int H = j.H;
     const uint32_t* off = j.col_cnt + (int64_t)img * (j.W + 1);
     const int64_t rbase = (int64_t)img * j.run_cap;
     const int nr = min((int)off[j.W], j.run_cap);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const bool in_lds = nr <= kLdsRuns;
+    int* parent = in_lds ? lds_parent : (j.parent + rbase);          // k_runs_fill initialised the global array to identity
+    uint32_t* rowcnt = j.rowcnt + (int64_t)img * (H + 1);
+    uint32_t* rowpos = j.rowpos + (int64_t)img * (H + 1);
+    if (in_lds) for (int i = t; i < nr; i += 1024) lds_parent[i] = i;
+    if (t == 0) s_label00 = 0;
+    __syncthreads();
+
+    // ---- union
+    for (int i = t; i < nr; i += 1024) {
         const int c = j.run_col[rbase + i];
         if (c + 1 >= j.W) continue;
         const uint32_t se = j.run_se[rbase + i];
@@ -160,35 +186,26 @@ __global__ __launch_bounds__(256) void k_union(Job j) {
         }
         for (int q = lo; q < end; ++q) {
             if ((int)(j.run_se[rbase + q] & 0xffffu) > b + 1) break;
-            uf_unite(j, rbase, i, q);
+            uf_unite(j, rbase, parent, i, q);
         }
     }
-}
+    __threadfence_block();
+    __syncthreads();
 
-// after k_union: point every run at its root, fold area / bbox into the root, list the roots and count them per row.
-// Runs of one component sit next to each other in the run list (adjacent columns), so the lanes of a wave mostly share
-// a root: they are combined with wave reductions and ONE lane issues the atomics (otherwise every run of a strip
-// would queue five atomics on the same five words).
-__global__ __launch_bounds__(256) void k_flatten(Job j) {
-    const int img = blockIdx.y;
-    const uint32_t* off = j.col_cnt + (int64_t)img * (j.W + 1);
-    const int64_t rbase = (int64_t)img * j.run_cap;
-    const int nr = min((int)off[j.W], j.run_cap);
-    int* parent = j.parent + rbase;
-    uint32_t* rowcnt = j.rowcnt + (int64_t)img * (j.H + 1);
-    const int lane = threadIdx.x & 63;
-    for (int i0 = blockIdx.x * blockDim.x; i0 < nr; i0 += gridDim.x * blockDim.x) {
-        const int i = i0 + threadIdx.x;
+    // ---- flatten
+    for (int i0 = 0; i0 < nr; i0 += 1024) {
+        const int i = i0 + t;
         const bool active = i < nr;
         int r = i, s = 0, e = -1, c = 0;
         if (active) {
-            for (;;) { const int p = __hip_atomic_load(&parent[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (p == r) break; r = p; }
+            r = uf_find_live(parent, i);
             const uint32_t se = j.run_se[rbase + i];
             s = (int)(se & 0xffffu); e = (int)(se >> 16); c = j.run_col[rbase + i];
-            if (r != i) __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else {                                                   // a root: its run starts at the component's raster-first pixel
+            if (r != i) __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // shortens later finds
+            if (in_lds) j.parent[rbase + i] = r;                     // the global copy is what lfa_debug_fetch paints from
+            if (r == i) {                                            // a root: its run starts at the component's raster-first pixel
                 atomicAdd(&rowcnt[s], 1u);
-                j.rootlist[rbase + atomicAdd(&rowcnt[j.H], 1u)] = i;
+                j.rootlist[rbase + atomicAdd(&rowcnt[H], 1u)] = i;
             }
         }
         const bool need = active && r != i;
@@ -209,28 +226,15 @@ __global__ __launch_bounds__(256) void k_flatten(Job j) {
             todo &= ~grp;
         }
     }
-}
+    __threadfence_block();
+    __syncthreads();
 
-// Label ids: scipy.ndimage.label numbers the components in raster order of their first pixel, i.e. label = 1 + rank of
-// the root run's (row, col) among all roots.  Roots are few (tens to a few thousand) next to H*W pixels, so they are
-// ranked as a list: counted per row by k_flatten, rows prefix-summed here, roots dropped into their row's bucket, and
-// each root's rank = roots in earlier rows + roots of its own row further left.  One 1024-thread block per image.
-__global__ __launch_bounds__(1024) void k_rank_roots(Job j) {
-    const int img = blockIdx.x;
-    const int H = j.H;
-    uint32_t* rowcnt = j.rowcnt + (int64_t)img * (H + 1);
-    uint32_t* rowpos = j.rowpos + (int64_t)img * (H + 1);
-    const int64_t rbase = (int64_t)img * j.run_cap;
-    const int K = min((int)rowcnt[H], j.run_cap);
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    __shared__ uint32_t wsum[16];
-    __shared__ int s_label00;
-    if (t == 0) s_label00 = 0;
-    // exclusive prefix over the rows: a contiguous segment of rows per thread, block scan of the segment sums
+    // ---- rank
+    const int K = min((int)__hip_atomic_load(&rowcnt[H], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), j.run_cap);
     const int seg = (H + 1023) / 1024;
     const int r0 = min(H, t * seg), r1 = min(H, r0 + seg);
     uint32_t sum = 0;
-    for (int r = r0; r < r1; ++r) sum += rowcnt[r];
+    for (int r = r0; r < r1; ++r) sum += __hip_atomic_load(&rowcnt[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t inc = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
@@ -238,19 +242,21 @@ __global__ __launch_bounds__(1024) void k_rank_roots(Job j) {
     __syncthreads();
     uint32_t run = inc - sum;
     for (int q = 0; q < wv; ++q) run += wsum[q];
-    for (int r = r0; r < r1; ++r) { const uint32_t c = rowcnt[r]; rowcnt[r] = run; rowpos[r] = run; run += c; }   // rowcnt becomes the offsets
+    for (int r = r0; r < r1; ++r) {                                  // rowcnt becomes the offsets, rowpos the fill cursors
+        const uint32_t c = __hip_atomic_load(&rowcnt[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rowcnt[r] = run; rowpos[r] = run; run += c;
+    }
     __threadfence_block();
     __syncthreads();
-    // roots into the buckets of their rows
     for (int q = t; q < K; q += 1024) {
-        const int i = j.rootlist[rbase + q];
+        const int i = __hip_atomic_load(&j.rootlist[rbase + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int s = (int)(j.run_se[rbase + i] & 0xffffu);
         j.bucket[rbase + atomicAdd(&rowpos[s], 1u)] = i;
     }
     __threadfence_block();
     __syncthreads();
     for (int q = t; q < K; q += 1024) {
-        const int i = j.rootlist[rbase + q];
+        const int i = __hip_atomic_load(&j.rootlist[rbase + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int s = (int)(j.run_se[rbase + i] & 0xffffu), c = j.run_col[rbase + i];
         const uint32_t lo = __hip_atomic_load(&rowcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t hi = __hip_atomic_load(&rowpos[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -275,13 +281,7 @@ hipError_t launch_label(const Job& j, hipStream_t s) {
     LFA_LAUNCH("k_runs_count", k_runs_count, gcol, dim3(256), 0, s, j);
     LFA_LAUNCH("k_col_scan", k_col_scan, dim3(j.n), dim3(256), 0, s, j);
     LFA_LAUNCH("k_runs_fill", k_runs_fill, gcol, dim3(256), 0, s, j);
-    int gx = (4096 + j.n - 1) / j.n;
-    if (gx < 8) gx = 8;
-    if (gx > 256) gx = 256;
-    const dim3 grun(gx, j.n);
-    LFA_LAUNCH("k_union", k_union, grun, dim3(256), 0, s, j);
-    LFA_LAUNCH("k_flatten", k_flatten, grun, dim3(256), 0, s, j);
-    LFA_LAUNCH("k_rank_roots", k_rank_roots, dim3(j.n), dim3(1024), 0, s, j);
+    LFA_LAUNCH("k_components", k_components, dim3(j.n), dim3(1024), 0, s, j);
     return hipGetLastError();
 }
 
