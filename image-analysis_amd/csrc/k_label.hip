@@ -17,6 +17,7 @@
 // hot path (lfa_debug_fetch paints it for tests).
 #include "lfa_internal.h"
 #include "lfa_device.h"
+#include "lfa_regions.h"
 
 namespace lfa {
 
@@ -65,52 +66,6 @@ __global__ __launch_bounds__(256) void k_runs_count(Job j) {
     j.col_cnt[(int64_t)img * (j.W + 1) + c] = (uint32_t)n;
 }
 
-// exclusive scan of the W per-column counts of one image (in place), total at [W]
-__global__ __launch_bounds__(256) void k_col_scan(Job j) {
-    const int img = blockIdx.x;
-    uint32_t* cc = j.col_cnt + (int64_t)img * (j.W + 1);
-    __shared__ uint32_t part[256];
-    const int t = threadIdx.x;
-    const int seg = (j.W + 255) / 256;
-    const int b0 = min(j.W, t * seg), b1 = min(j.W, b0 + seg);
-    uint32_t sum = 0;
-    for (int k = b0; k < b1; ++k) sum += cc[k];
-    part[t] = sum;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t acc = 0;
-        for (int k = 0; k < 256; ++k) { const uint32_t v = part[k]; part[k] = acc; acc += v; }
-        cc[j.W] = acc;
-        j.info[img].n_runs = (int)acc;
-        if (acc > (uint32_t)j.run_cap) j.info[img].status |= 2;
-    }
-    __syncthreads();
-    uint32_t acc = part[t];
-    for (int k = b0; k < b1; ++k) { const uint32_t v = cc[k]; cc[k] = acc; acc += v; }
-}
-
-__global__ __launch_bounds__(256) void k_runs_fill(Job j) {
-    const int img = blockIdx.y;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= j.W) return;
-    const int64_t rbase = (int64_t)img * j.run_cap;
-    const uint32_t* cc = j.col_cnt + (int64_t)img * (j.W + 1);
-    const uint32_t first = cc[c], cap = (uint32_t)j.run_cap;
-    const uint32_t end = min(cc[c + 1], cap);
-    const uint32_t* tmp = j.run_tmp + rbase + (int64_t)c * j.runs_per_col;
-    for (uint32_t idx = first; idx < end; ++idx) {
-        const uint32_t se = tmp[idx - first];
-        const int s = (int)(se & 0xffffu), e = (int)(se >> 16);
-        const int64_t i = rbase + idx;
-        j.run_se[i] = se;
-        j.run_col[i] = (uint16_t)c;
-        j.parent[i] = (int)idx;
-        j.area[i] = e - s + 1;
-        int4 bb; bb.x = s; bb.y = c; bb.z = e + 1; bb.w = c + 1;
-        *(int4*)(j.bbox + i * 4) = bb;
-    }
-}
-
 // ---- union-find on runs ---------------------------------------------------------------------------------------------
 // Links always point to the run with the smaller key (row_start * W + col), so chains strictly descend, there are no
 // cycles, and the root of a finished component is the run holding its raster-first pixel.  parent[] is read with
@@ -157,12 +112,54 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
     __shared__ int lds_parent[kLdsRuns];
     __shared__ uint32_t wsum[16];
     __shared__ int s_label00;
+    __shared__ int s_wcnt[16], s_base;
     const int img = blockIdx.x;
-    const int H = j.H;
-    const uint32_t* off = j.col_cnt + (int64_t)img * (j.W + 1);
+    const int H = j.H, W = j.W;
+    uint32_t* off = j.col_cnt + (int64_t)img * (W + 1);
     const int64_t rbase = (int64_t)img * j.run_cap;
-    const int nr = min((int)off[j.W], j.run_cap);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+
+    // ---- run list: exclusive scan of the per-column counts (in place, total at [W]), then the runs k_runs_count parked
+    //      per column move to their place in the compact, column-major list
+    {
+        const int seg = (W + 1023) / 1024;
+        const int c0 = min(W, t * seg), c1 = min(W, c0 + seg);
+        uint32_t sum = 0;
+        for (int c = c0; c < c1; ++c) sum += off[c];
+        uint32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum, total = 0;
+        for (int q = 0; q < 16; ++q) { const uint32_t v = wsum[q]; total += v; if (q < wv) run += v; }
+        const uint32_t cap = (uint32_t)j.run_cap;
+        for (int c = c0; c < c1; ++c) {
+            const uint32_t cnt = off[c];
+            off[c] = run;
+            const uint32_t* tmp = j.run_tmp + rbase + (int64_t)c * j.runs_per_col;
+            for (uint32_t k = 0; k < cnt && run + k < cap; ++k) {
+                const uint32_t se = tmp[k];
+                const int s = (int)(se & 0xffffu), e = (int)(se >> 16);
+                const int64_t i = rbase + run + k;
+                j.run_se[i] = se;
+                j.run_col[i] = (uint16_t)c;
+                j.parent[i] = (int)(run + k);
+                j.area[i] = e - s + 1;
+                int4 bb; bb.x = s; bb.y = c; bb.z = e + 1; bb.w = c + 1;
+                *(int4*)(j.bbox + i * 4) = bb;
+            }
+            run += cnt;
+        }
+        if (t == 0) {
+            off[W] = total;
+            j.info[img].n_runs = (int)total;
+            if (total > cap) atomicOr(&j.info[img].status, 2);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    const int nr = min((int)__hip_atomic_load(&off[W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), j.run_cap);
     const bool in_lds = nr <= kLdsRuns;
     int* parent = in_lds ? lds_parent : (j.parent + rbase);          // k_runs_fill initialised the global array to identity
     uint32_t* rowcnt = j.rowcnt + (int64_t)img * (H + 1);
@@ -270,8 +267,12 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
         j.label_of_run[rbase + i] = lab;
         if (s == 0 && c == 0) s_label00 = 1;                // pixel (0,0) is foreground <=> it is the first pixel of label 1
     }
+    __threadfence_block();
     __syncthreads();
     if (t == 0) { j.info[img].n_labels = K; j.info[img].label00 = s_label00; }
+
+    // ---- candidate list for the region test (k_regions.hip)
+    candidates_phase<1024>(j, img, K, s_label00, s_wcnt, &s_base);
 }
 
 hipError_t launch_label(const Job& j, hipStream_t s) {
@@ -279,8 +280,6 @@ hipError_t launch_label(const Job& j, hipStream_t s) {
     hipError_t e = hipMemsetAsync(j.rowcnt, 0, (size_t)j.n * (j.H + 1) * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     LFA_LAUNCH("k_runs_count", k_runs_count, gcol, dim3(256), 0, s, j);
-    LFA_LAUNCH("k_col_scan", k_col_scan, dim3(j.n), dim3(256), 0, s, j);
-    LFA_LAUNCH("k_runs_fill", k_runs_fill, gcol, dim3(256), 0, s, j);
     LFA_LAUNCH("k_components", k_components, dim3(j.n), dim3(1024), 0, s, j);
     return hipGetLastError();
 }

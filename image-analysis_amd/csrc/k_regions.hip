@@ -10,74 +10,11 @@
 // analysis window into a per-image pool; the profile stage of lfa_analyze_batch then needs no second read of the pixels.
 #include "lfa_internal.h"
 #include "lfa_device.h"
+#include "lfa_regions.h"
 
 namespace lfa {
 
 constexpr int kMaxStripsLds = 1024;
-
-constexpr int kWinRowsLds = 2048;
-
-struct Box { int minr, minc, maxr, maxc;      // expanded, NOT clipped (detection.py:73-74)
-             int cr, cc; };                   // clipped ends (numpy slicing)
-
-__device__ inline Box cand_box(const Job& j, int64_t rbase, int root) {
-    const int* bb = j.bbox + (rbase + root) * 4;
-    Box b;
-    b.minr = bb[0]; b.minc = bb[1];
-    b.maxr = max(bb[2], b.minr + j.min_maxr); b.maxc = max(bb[3], b.minc + j.min_maxc);
-    b.cr = min(b.maxr, j.H); b.cc = min(b.maxc, j.W);
-    return b;
-}
-
-// labels with area >= 100, ascending, one block per image; then pool offsets for the window row sums
-__global__ __launch_bounds__(256) void k_candidates(Job j) {
-    const int img = blockIdx.x;
-    const int64_t rbase = (int64_t)img * j.run_cap;
-    const int64_t cbase = (int64_t)img * j.cand_cap;
-    const int K = j.info[img].n_labels;
-    __shared__ int wcnt[4];
-    __shared__ int base;
-    const int t = threadIdx.x, wv = t >> 6, lane = t & 63;
-    if (t == 0) base = 0;
-    __syncthreads();
-    for (int l0 = 0; l0 < K; l0 += 256) {
-        const int l = l0 + t;
-        bool flag = false;
-        if (l < K) flag = j.area[rbase + j.root_of_label[rbase + l]] >= kAreaMin;
-        const unsigned long long bal = __ballot(flag);
-        if (lane == 0) wcnt[wv] = __popcll(bal);
-        __syncthreads();
-        int offs = base;
-        for (int k = 0; k < wv; ++k) offs += wcnt[k];
-        if (flag) {
-            const int64_t slot = cbase + offs + __popcll(bal & ((1ull << lane) - 1ull));
-            j.cand[slot] = l + 1;
-            j.cand_sum[slot * 3 + 0] = 0; j.cand_sum[slot * 3 + 1] = 0; j.cand_sum[slot * 3 + 2] = 0;
-            j.cand_rs_off[slot] = -1;
-        }
-        __syncthreads();
-        if (t == 0) base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
-    }
-    if (t != 0) return;
-    const int nc = base;
-    j.info[img].n_candidates = nc;
-    // window row-sum pool: first come first served in label order; needs the dword path of k_box_sums
-    const int esz = (j.dtype == LFA_U16) ? 2 : 1;
-    const bool fast = j.aligned16 && ((((int64_t)j.W * j.C * esz) & 3) == 0);
-    if (!fast || j.info[img].label00 == 0) return;            // no box pass for this image (see k_box_sums): no pooled rows
-    int used = 0;
-    for (int ci = 0; ci < nc && ci < 4096; ++ci) {
-        const Box b = cand_box(j, rbase, j.root_of_label[rbase + j.cand[cbase + ci] - 1]);
-        const int h = b.cr - b.minr, w = b.cc - b.minc;
-        const int len = (int)((double)h * .6) - (int)((double)h * .25);
-        const int ne = ((int)((double)w * .7) - (int)((double)w * .3)) * j.C;
-        if (len <= 0 || len > kWinRowsLds || ne <= 0 || (esz == 2 && ne > 65536)) continue;
-        if (used + len > j.rowsum_cap) break;
-        j.cand_rs_off[cbase + ci] = used;
-        used += len;
-    }
-}
 
 // Integer sums of the ORIGINAL image over the expanded, clipped box of every candidate (per channel for colour).
 // One block per candidate.  Rows are read as aligned dwords (a row of a strip is ~170 bytes) and every (row, dword)
@@ -280,7 +217,6 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
 }
 
 hipError_t launch_regions(const Job& j, const OutPtrs& o, hipStream_t s) {
-    LFA_LAUNCH("k_candidates", k_candidates, dim3(j.n), dim3(256), 0, s, j);
     int gx = (8192 + j.n - 1) / j.n;                       // one block per candidate; blocks loop when there are more
     if (gx < 16) gx = 16;
     if (gx > 256) gx = 256;
