@@ -277,8 +277,6 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
 
 hipError_t launch_label(const Job& j, hipStream_t s) {
     const dim3 gcol((j.W + 255) / 256, j.n);
-    hipError_t e = hipMemsetAsync(j.rowcnt, 0, (size_t)j.n * (j.H + 1) * sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
     LFA_LAUNCH("k_runs_count", k_runs_count, gcol, dim3(256), 0, s, j);
     LFA_LAUNCH("k_components", k_components, dim3(j.n), dim3(1024), 0, s, j);
     return hipGetLastError();

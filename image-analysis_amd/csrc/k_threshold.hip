@@ -19,16 +19,27 @@ namespace lfa {
 // ------------------------------------------------------------------------------------------------------------------
 // init
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void k_init_info(Job j) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= j.n) return;
-    LfaImageInfo z;
-    z.xmin = 0x7fffffff; z.xmax = -1; z.v_thr = 0; z.x_thr = 0x7fffffff;
-    z.gmin = __longlong_as_double(0x7ff0000000000000LL); z.gmax = 0.0;
-    z.vmin = 0.0; z.vmax = 0.0; z.v_thr_f = 0.0; z.g_thr = __longlong_as_double(0x7ff0000000000000LL);
-    z.otsu_bin = -1; z.all_equal = 0; z.ambiguous = 0;
-    z.n_runs = 0; z.n_labels = 0; z.label00 = 0; z.n_candidates = 0; z.n_accepted = 0; z.n_strips = 0; z.status = 0;
-    j.info[i] = z;
+// One launch resets everything a call accumulates into: the per-image info records, the 256-bin histograms (uint8 and
+// colour images; the uint16 histogram is cleared over its occupied range by k_zero_hist_u16 once min/max are known) and
+// the per-row root counters of the labelling stage.  Grid: (blocks, n); block x of image y strides over the words.
+__global__ __launch_bounds__(256) void k_init_info(Job j) {
+    const int img = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    if (t == 0) {
+        LfaImageInfo z;
+        z.xmin = 0x7fffffff; z.xmax = -1; z.v_thr = 0; z.x_thr = 0x7fffffff;
+        z.gmin = __longlong_as_double(0x7ff0000000000000LL); z.gmax = 0.0;
+        z.vmin = 0.0; z.vmax = 0.0; z.v_thr_f = 0.0; z.g_thr = __longlong_as_double(0x7ff0000000000000LL);
+        z.otsu_bin = -1; z.all_equal = 0; z.ambiguous = 0;
+        z.n_runs = 0; z.n_labels = 0; z.label00 = 0; z.n_candidates = 0; z.n_accepted = 0; z.n_strips = 0; z.status = 0;
+        j.info[img] = z;
+    }
+    if (j.hist_stride == 256) {
+        uint32_t* gh = j.hist + (int64_t)img * 256;
+        for (int k = t; k < 256; k += nt) gh[k] = 0;
+    }
+    uint32_t* rc = j.rowcnt + (int64_t)img * (j.H + 1);
+    for (int k = t; k <= j.H; k += nt) rc[k] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -604,18 +615,14 @@ static int blocks_per_image(const Job& j, int px_per_block) {
     }
 
 hipError_t launch_threshold(const Job& j, hipStream_t s) {
-    LFA_LAUNCH("k_init_info", k_init_info, dim3((j.n + 255) / 256), dim3(256), 0, s, j);
+    LFA_LAUNCH("k_init_info", k_init_info, dim3(j.H >= 4096 ? 8 : 2, j.n), dim3(256), 0, s, j);
     if (j.C == 3) {
-        hipError_t e = hipMemsetAsync(j.hist, 0, (size_t)j.n * j.hist_stride * sizeof(uint32_t), s);
-        if (e != hipSuccess) return e;
         const dim3 grid(blocks_per_image(j, 256 * 64), j.n);
         LFA_DISPATCH_V(k_minmax_rgb, grid, dim3(256), s, j);
         LFA_LAUNCH("k_edges_rgb", k_edges_rgb, dim3(j.n), dim3(320), 0, s, j);
         LFA_DISPATCH_V(k_hist_rgb, grid, dim3(256), s, j);
         LFA_LAUNCH("k_otsu_rgb", k_otsu_rgb, dim3(j.n), dim3(256), 0, s, j);
     } else if (j.dtype == LFA_U8) {
-        hipError_t e = hipMemsetAsync(j.hist, 0, (size_t)j.n * j.hist_stride * sizeof(uint32_t), s);
-        if (e != hipSuccess) return e;
         const dim3 grid(blocks_per_image(j, 256 * 128), j.n);
         LFA_LAUNCH("k_hist_u8", k_hist_u8, grid, dim3(256), 0, s, j);
         LFA_LAUNCH("k_otsu_int", k_otsu_int, dim3(j.n), dim3(256), 0, s, j);
