@@ -44,29 +44,56 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
             const uint32_t best = (uint32_t)inf.otsu_bin;
             const uint32_t best4 = best * 0x01010101u;
             const uint8_t* bp = j.bins + (int64_t)img * H * W + (int64_t)r0 * W + (int64_t)cg * 16;
+            // Four pixels per instruction: byte x > best  <=>  x + (255 - best) carries out of its byte (best <= 254), and the
+            // carry of every byte of a dword comes from one add on the low 7 bits plus the majority of the three top bits.
+            // The carries (bit 7 of each byte) of eight consecutive rows are shifted into one dword per pixel quad,
+            // S[j][d]: byte b = pixel 4d+b, bit i = row 8j+i -- which is byte j of that pixel's vertical 64-row word.
+            const uint32_t c4 = (255u - best) * 0x01010101u, c4lo = c4 & 0x7f7f7f7fu;
+            uint32_t S[8][4];
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) {
+                uint4 av[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)                               // the eight rows of this byte are requested together
+                    av[i] = (jb * 8 + i < rows) ? *(const uint4*)(bp + (int64_t)(jb * 8 + i) * W) : make_uint4(0u, 0u, 0u, 0u);
+                uint32_t acc4[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int i = 7; i >= 0; --i) {                            // top row first: it ends up shifted to bit 7
+                    const int r = jb * 8 + i;
+                    const uint32_t w[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
+                    uint32_t t[4], anyeq = 0;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const uint32_t x = w[d];
+                        const uint32_t low = (x & 0x7f7f7f7fu) + c4lo;
+                        t[d] = (((x & c4) | ((x | c4) & low)) & 0x80808080u) >> 7;
+                        const uint32_t v = x ^ best4;                    // a zero byte <=> that pixel is in bin `best`
+                        anyeq |= (v - 0x01010101u) & ~v;
+                    }
+                    if ((anyeq & 0x80808080u) && r < rows) {              // settle those pixels on the image itself
+                        const uint8_t* q = base + ((int64_t)(r0 + r) * W + (int64_t)cg * 16) * 3;
+#pragma unroll
+                        for (int k = 0; k < 16; ++k)
+                            if (byte_of(w, k) == best && (2125u * q[3 * k] + 7154u * q[3 * k + 1] + 721u * q[3 * k + 2]) >= G_thr)
+                                t[k >> 2] |= 1u << (8 * (k & 3));
+                    }
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) acc4[d] = (acc4[d] << 1) | ((r < rows) ? t[d] : 0u);
+                }
+#pragma unroll
+                for (int d = 0; d < 4; ++d) S[jb][d] = acc4[d];
+            }
+            // column k = 4d+b: low word = byte b of S[0..3][d], high word = byte b of S[4..7][d]
             uint32_t lo[16], hi[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { lo[k] = 0; hi[k] = 0; }
-            auto brow = [&](int r, uint32_t (&acc)[16], uint32_t rbit) {
-                const uint4 a = *(const uint4*)(bp + (int64_t)r * W);
-                const uint32_t w[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-                for (int k = 0; k < 16; ++k) acc[k] |= (byte_of(w, k) > best) ? rbit : 0u;
-                uint32_t anyeq = 0;                                  // a zero byte in w ^ best4 <=> some pixel is in bin `best`
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { const uint32_t v = w[q] ^ best4; anyeq |= (v - 0x01010101u) & ~v & 0x80808080u; }
-                if (anyeq) {
-                    const uint8_t* q = base + ((int64_t)(r0 + r) * W + (int64_t)cg * 16) * 3;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        if (byte_of(w, k) == best && (2125u * q[3 * k] + 7154u * q[3 * k + 1] + 721u * q[3 * k + 2]) >= G_thr) acc[k] |= rbit;
-                }
-            };
-            const int rows_lo = min(rows, 32);
-#pragma unroll 4
-            for (int r = 0; r < rows_lo; ++r) brow(r, lo, 1u << r);
-#pragma unroll 4
-            for (int r = 32; r < rows; ++r) brow(r, hi, 1u << (r - 32));
+            for (int k = 0; k < 16; ++k) {
+                const int d = k >> 2, bsel = k & 3;
+                const uint32_t sel = (uint32_t)(((4 + bsel) << 8) | bsel);          // byte0 = second operand's byte b, byte1 = first's
+                const uint32_t p01 = __builtin_amdgcn_perm(S[1][d], S[0][d], sel), p23 = __builtin_amdgcn_perm(S[3][d], S[2][d], sel);
+                const uint32_t p45 = __builtin_amdgcn_perm(S[5][d], S[4][d], sel), p67 = __builtin_amdgcn_perm(S[7][d], S[6][d], sel);
+                lo[k] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                hi[k] = __builtin_amdgcn_perm(p67, p45, 0x05040100u);
+            }
             uint64_t* o = out + (int64_t)rb * W + cg * 16;
 #pragma unroll
             for (int k = 0; k < 16; k += 2) {
