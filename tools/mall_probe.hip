@@ -23,6 +23,18 @@ __global__ __launch_bounds__(256) void k_read(const uint4* p, size_t n16, unsign
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// the histogram pass's traffic shape: 48 bytes in, 16 bytes out per lane and step
+__global__ __launch_bounds__(256) void k_read3_write1(const uint4* p, uint4* q, size_t ngroups) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; g < ngroups; g += step) {
+        const uint4 a = p[3 * g], b = p[3 * g + 1], c = p[3 * g + 2];
+        uint4 o;
+        o.x = a.x ^ b.x ^ c.x; o.y = a.y ^ b.y ^ c.y; o.z = a.z ^ b.z ^ c.z; o.w = a.w ^ b.w ^ c.w;
+        q[g] = o;
+    }
+}
+
 static int grid_for(size_t n16) {
     size_t blocks = (n16 + 256 * 8 - 1) / (256 * 8);      // about 8 x 16 bytes per lane
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -67,6 +79,20 @@ int main() {
         }
         const size_t covered = (total / S) * S;
         printf("3pass_groups,%zu,%.4f,%.1f\n", groups[gi], best, (double)covered * 3 / (best * 1e6));
+    }
+    {
+        const size_t in_bytes = (size_t)2304 << 20, ngroups = in_bytes / 48;       // 2.25 GiB in, 0.75 GiB out
+        uint4* q = (uint4*)(buf + in_bytes);
+        for (int blocks : {1024, 2048, 4096, 8192}) {
+            for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_read3_write1, dim3(blocks), dim3(256), 0, s, (const uint4*)buf, q, ngroups);
+            CK(hipEventRecord(e0, s));
+            const int reps = 10;
+            for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_read3_write1, dim3(blocks), dim3(256), 0, s, (const uint4*)buf, q, ngroups);
+            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("read48_write16_blocks%d,%zu,%.4f,%.1f\n", blocks, (in_bytes + ngroups * 16) >> 20, ms / reps,
+                   (double)(in_bytes + ngroups * 16) * reps / (ms * 1e6));
+        }
     }
     CK(hipGetLastError());
     return 0;
