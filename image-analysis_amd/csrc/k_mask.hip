@@ -33,64 +33,77 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
         G_thr = eg[kEdgesI_MaskThr];
         integer_path = eg[kEdgesI_MaskCrit] == 0;
         if (VEC && j.bins && eg[kEdgesI_Bins]) {
-            // the bin plane k_hist_rgb wrote decides every pixel outside the threshold's own bin: 1 byte per pixel
-            // instead of 3; a pixel IN that bin is settled by the exact compare on the image itself
+            // The class plane k_hist_rgb wrote (bin >> 4 of every pixel, 4 bits each) decides every pixel whose class
+            // differs from the class q of the Otsu bin: class > q: set, class < q: clear -- half a byte per pixel
+            // instead of three.  A pixel of class q is settled by the exact compare on the image itself.
             const int ncg = W >> 4;
             const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
             if (item >= (int64_t)j.HB * ncg) return;
             const int rb = (int)(item / ncg), cg = (int)(item % ncg);
             const int r0 = rb * 64;
             const int rows = min(64, H - r0);
-            const uint32_t best = (uint32_t)inf.otsu_bin;
-            const uint32_t best4 = best * 0x01010101u;
-            const uint8_t* bp = j.bins + (int64_t)img * H * W + (int64_t)r0 * W + (int64_t)cg * 16;
-            // Four pixels per instruction: byte x > best  <=>  x + (255 - best) carries out of its byte (best <= 254), and the
-            // carry of every byte of a dword comes from one add on the low 7 bits plus the majority of the three top bits.
-            // The carries (bit 7 of each byte) of eight consecutive rows are shifted into one dword per pixel quad,
-            // S[j][d]: byte b = pixel 4d+b, bit i = row 8j+i -- which is byte j of that pixel's vertical 64-row word.
-            const uint32_t c4 = (255u - best) * 0x01010101u, c4lo = c4 & 0x7f7f7f7fu;
-            uint32_t S[8][4];
+            const uint32_t q = (uint32_t)inf.otsu_bin >> 4;
+            const uint32_t q8 = q * 0x11111111u;
+            const uint8_t* bp = j.bins + (((int64_t)img * H * W + (int64_t)r0 * W) >> 1) + (int64_t)cg * 8;
+            const int64_t rowb = (int64_t)W >> 1;
+            // Eight pixels per instruction: nibble x > q  <=>  x + (15 - q) carries out of its nibble, and the carries of
+            // all nibbles of a dword come from one add on the low 3 bits of each plus the majority of the three top
+            // bits.  The carries (bit 3 of each nibble) are split into even and odd pixels -- each then one bit per
+            // byte -- and the bits of eight consecutive rows are shifted into those bytes:
+            //   Se[j][d] byte m = pixel 8d+2m, So[j][d] byte m = pixel 8d+2m+1, bit i = row 8j+i
+            // which is byte j of that pixel's vertical 64-row word.
+            const uint32_t c8 = (15u - q) * 0x11111111u, c8lo = c8 & 0x77777777u;
+            uint32_t Se[8][2], So[8][2];
 #pragma unroll
             for (int jb = 0; jb < 8; ++jb) {
-                uint4 av[8];
+                uint2 av[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i)                               // the eight rows of this byte are requested together
-                    av[i] = (jb * 8 + i < rows) ? *(const uint4*)(bp + (int64_t)(jb * 8 + i) * W) : make_uint4(0u, 0u, 0u, 0u);
-                uint32_t acc4[4] = {0u, 0u, 0u, 0u};
+                    av[i] = (jb * 8 + i < rows) ? *(const uint2*)(bp + (int64_t)(jb * 8 + i) * rowb) : make_uint2(0u, 0u);
+                uint32_t ae[2] = {0u, 0u}, ao[2] = {0u, 0u};
 #pragma unroll
                 for (int i = 7; i >= 0; --i) {                            // top row first: it ends up shifted to bit 7
                     const int r = jb * 8 + i;
-                    const uint32_t w[4] = {av[i].x, av[i].y, av[i].z, av[i].w};
-                    uint32_t t[4], anyeq = 0;
+                    const uint32_t w[2] = {av[i].x, av[i].y};
+                    uint32_t car[2], anyeq = 0;
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) {
+                    for (int d = 0; d < 2; ++d) {
                         const uint32_t x = w[d];
-                        const uint32_t low = (x & 0x7f7f7f7fu) + c4lo;
-                        t[d] = (((x & c4) | ((x | c4) & low)) & 0x80808080u) >> 7;
-                        const uint32_t v = x ^ best4;                    // a zero byte <=> that pixel is in bin `best`
-                        anyeq |= (v - 0x01010101u) & ~v;
+                        const uint32_t low = (x & 0x77777777u) + c8lo;
+                        car[d] = ((x & c8) | ((x | c8) & low)) & 0x88888888u;
+                        const uint32_t v = x ^ q8;                       // a zero nibble <=> that pixel is of class q
+                        anyeq |= (v - 0x11111111u) & ~v;
                     }
-                    if ((anyeq & 0x80808080u) && r < rows) {              // settle those pixels on the image itself
-                        const uint8_t* q = base + ((int64_t)(r0 + r) * W + (int64_t)cg * 16) * 3;
+                    if ((anyeq & 0x88888888u) && r < rows) {              // settle those pixels on the image itself
+                        const uint8_t* px = base + ((int64_t)(r0 + r) * W + (int64_t)cg * 16) * 3;
 #pragma unroll
                         for (int k = 0; k < 16; ++k)
-                            if (byte_of(w, k) == best && (2125u * q[3 * k] + 7154u * q[3 * k + 1] + 721u * q[3 * k + 2]) >= G_thr)
-                                t[k >> 2] |= 1u << (8 * (k & 3));
+                            if (((w[k >> 3] >> (4 * (k & 7))) & 15u) == q &&
+                                (2125u * px[3 * k] + 7154u * px[3 * k + 1] + 721u * px[3 * k + 2]) >= G_thr)
+                                car[k >> 3] |= 8u << (4 * (k & 7));
                     }
+                    const bool valid = r < rows;
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) acc4[d] = (acc4[d] << 1) | ((r < rows) ? t[d] : 0u);
+                    for (int d = 0; d < 2; ++d) {
+                        const uint32_t c = valid ? car[d] : 0u;
+                        ae[d] = (ae[d] << 1) | ((c >> 3) & 0x01010101u);
+                        ao[d] = (ao[d] << 1) | ((c >> 7) & 0x01010101u);
+                    }
                 }
 #pragma unroll
-                for (int d = 0; d < 4; ++d) S[jb][d] = acc4[d];
+                for (int d = 0; d < 2; ++d) { Se[jb][d] = ae[d]; So[jb][d] = ao[d]; }
             }
-            // column k = 4d+b: low word = byte b of S[0..3][d], high word = byte b of S[4..7][d]
+            // column k = 8d + 2m + odd: low word = byte m of S[0..3][d], high word = byte m of S[4..7][d]
             uint32_t lo[16], hi[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const int d = k >> 2, bsel = k & 3;
-                const uint32_t sel = (uint32_t)(((4 + bsel) << 8) | bsel);          // byte0 = second operand's byte b, byte1 = first's
-                const uint32_t p01 = __builtin_amdgcn_perm(S[1][d], S[0][d], sel), p23 = __builtin_amdgcn_perm(S[3][d], S[2][d], sel);
-                const uint32_t p45 = __builtin_amdgcn_perm(S[5][d], S[4][d], sel), p67 = __builtin_amdgcn_perm(S[7][d], S[6][d], sel);
+                const int d = k >> 3, m = (k & 7) >> 1, odd = k & 1;
+                const uint32_t sel = (uint32_t)(((4 + m) << 8) | m);                // byte0 = second operand's byte m, byte1 = first's
+                uint32_t b8[8];
+#pragma unroll
+                for (int jb = 0; jb < 8; ++jb) b8[jb] = odd ? So[jb][d] : Se[jb][d];
+                const uint32_t p01 = __builtin_amdgcn_perm(b8[1], b8[0], sel), p23 = __builtin_amdgcn_perm(b8[3], b8[2], sel);
+                const uint32_t p45 = __builtin_amdgcn_perm(b8[5], b8[4], sel), p67 = __builtin_amdgcn_perm(b8[7], b8[6], sel);
                 lo[k] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
                 hi[k] = __builtin_amdgcn_perm(p67, p45, 0x05040100u);
             }

@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
         return (ent & 0xffu) + ((G >= ((ent >> 8) & 0x3fffffu)) ? 1u : 0u);
     };
     auto walk = [&](uint32_t G, uint32_t k) -> uint32_t { while (G >= sg[k + 1]) ++k; return k; };   // sg[256..] = inf ends it
-    uint8_t* bins = j.bins ? j.bins + (int64_t)img * npix : nullptr;   // bin plane for k_mask (integer path only)
+    // class plane for k_mask (integer path only): bin >> 4 of every pixel, two pixels per byte (pixel 2q in the low nibble)
+    uint8_t* bins = j.bins ? j.bins + (int64_t)img * (npix >> 1) : nullptr;
     auto add = [&](double g) {                             // float64 path (an edge is critical): exact compares + census
         const float vf = __builtin_amdgcn_exp2f(0.4f * __builtin_amdgcn_logf((float)g));
         int k = (int)((vf - vminf) * scalef);
@@ -372,10 +373,10 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) kb[k] = walk(G[k], kb[k]);
                 }
-                uint32_t pk[4] = {0u, 0u, 0u, 0u};
+                uint32_t pk[2] = {0u, 0u};
 #pragma unroll
-                for (int k = 0; k < 16; ++k) { hadd(kb[k]); pk[k >> 2] |= kb[k] << (8 * (k & 3)); }
-                if (bins) *(uint4*)(bins + g * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                for (int k = 0; k < 16; ++k) { hadd(kb[k]); pk[k >> 3] |= (kb[k] >> 4) << (4 * (k & 7)); }
+                if (bins) *(uint2*)(bins + g * 8) = make_uint2(pk[0], pk[1]);
             }
             done = ng << 4;
         }
@@ -383,8 +384,7 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
             uint32_t flags = 0;
             const uint32_t G = gray_G(base[3 * p], base[3 * p + 1], base[3 * p + 2]);
             const uint32_t k = walk(G, binG(G, flags));
-            hadd(k);
-            if (bins) bins[p] = (uint8_t)k;
+            hadd(k);                                                  // (the plane is only used when H*W is a multiple of 16)
         }
     } else {
         if (j.aligned16) {

@@ -143,7 +143,7 @@ int ensure_workspace(LfaContext* h, int n, int H, int W, int C, int dtype, int L
     }
     if ((rc = ensure(h->edges, N * lfa::kEdges * 8))) return rc;
     if ((rc = ensure(h->edges_i, N * lfa::kEdgesI * 4))) return rc;
-    if (C == 3 && (rc = ensure(h->bins, N * (size_t)H * W))) return rc;
+    if (C == 3 && (rc = ensure(h->bins, N * (((size_t)H * W + 1) / 2)))) return rc;
     if ((rc = ensure(h->maskT, N * HB * W * 8))) return rc;
     if ((rc = ensure(h->col_cnt, N * (W + 1) * 4))) return rc;
     if ((rc = ensure(h->run_tmp, N * cap * 4))) return rc;

@@ -42,8 +42,9 @@ struct Job {
     double* otsu_s;          // [n][2][hist_stride]  the matching cumsum(counts*centers) arrays
     double* edges_g;         // [n][257]  gray-space bin edges (colour path)
     uint32_t* edges_i;       // [n][264]  the same as integer thresholds on G = 2125*b0 + 7154*b1 + 721*b2 (k_threshold.hip)
-    uint8_t* bins;           // [n][H*W]  colour path: histogram bin of every pixel, written by k_hist_rgb and read by k_mask
-                             //           instead of the image (1 byte per pixel instead of 3); null = not used
+    uint8_t* bins;           // [n][H*W/2]  colour path: class plane, (histogram bin >> 4) of every pixel in 4 bits, written by
+                             //             k_hist_rgb and read by k_mask instead of the image (0.5 byte per pixel instead of 3);
+                             //             null = not used
     uint64_t* maskT;         // [n][HB][W]      vertical 64-row words, thresholded image
     uint32_t* col_cnt;       // [n][W+1]        runs per column -> exclusive offsets
     uint32_t* run_tmp;       // [n][run_cap]    runs parked per column (runs_per_col slots each) between counting and compaction
