@@ -54,17 +54,21 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
             // which is byte j of that pixel's vertical 64-row word.
             const uint32_t c8 = (15u - q) * 0x11111111u, c8lo = c8 & 0x77777777u;
             uint32_t Se[8][2], So[8][2];
+            uint64_t eqrows = 0;                                          // rows holding a pixel of class q
 #pragma unroll
-            for (int jb = 0; jb < 8; ++jb) {
-                uint2 av[8];
+            for (int jq = 0; jq < 2; ++jq) {
+            uint2 av[32];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)                               // the eight rows of this byte are requested together
-                    av[i] = (jb * 8 + i < rows) ? *(const uint2*)(bp + (int64_t)(jb * 8 + i) * rowb) : make_uint2(0u, 0u);
+            for (int i = 0; i < 32; ++i)                                  // 32 rows are requested together
+                av[i] = (jq * 32 + i < rows) ? *(const uint2*)(bp + (int64_t)(jq * 32 + i) * rowb) : make_uint2(0u, 0u);
+#pragma unroll
+            for (int jh = 0; jh < 4; ++jh) {
+                const int jb = jq * 4 + jh;
                 uint32_t ae[2] = {0u, 0u}, ao[2] = {0u, 0u};
 #pragma unroll
                 for (int i = 7; i >= 0; --i) {                            // top row first: it ends up shifted to bit 7
                     const int r = jb * 8 + i;
-                    const uint32_t w[2] = {av[i].x, av[i].y};
+                    const uint32_t w[2] = {av[jh * 8 + i].x, av[jh * 8 + i].y};
                     uint32_t car[2], anyeq = 0;
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
@@ -74,15 +78,8 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
                         const uint32_t v = x ^ q8;                       // a zero nibble <=> that pixel is of class q
                         anyeq |= (v - 0x11111111u) & ~v;
                     }
-                    if ((anyeq & 0x88888888u) && r < rows) {              // settle those pixels on the image itself
-                        const uint8_t* px = base + ((int64_t)(r0 + r) * W + (int64_t)cg * 16) * 3;
-#pragma unroll
-                        for (int k = 0; k < 16; ++k)
-                            if (((w[k >> 3] >> (4 * (k & 7))) & 15u) == q &&
-                                (2125u * px[3 * k] + 7154u * px[3 * k + 1] + 721u * px[3 * k + 2]) >= G_thr)
-                                car[k >> 3] |= 8u << (4 * (k & 7));
-                    }
                     const bool valid = r < rows;
+                    eqrows |= (uint64_t)((valid && (anyeq & 0x88888888u)) ? 1u : 0u) << r;     // settled after the main loop
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
                         const uint32_t c = valid ? car[d] : 0u;
@@ -92,6 +89,7 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
                 }
 #pragma unroll
                 for (int d = 0; d < 2; ++d) { Se[jb][d] = ae[d]; So[jb][d] = ao[d]; }
+            }
             }
             // column k = 8d + 2m + odd: low word = byte m of S[0..3][d], high word = byte m of S[4..7][d]
             uint32_t lo[16], hi[16];
@@ -113,6 +111,20 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
                 uint4 v;
                 v.x = lo[k]; v.y = hi[k]; v.z = lo[k + 1]; v.w = hi[k + 1];
                 *(uint4*)(o + k) = v;
+            }
+            // Pixels of class q: the exact compare on the image itself.  Rare (the classes around the Otsu bin are the
+            // valley of the histogram), so this is a small rolled loop that ORs straight into the words just written
+            // -- this lane's own words -- instead of 64 unrolled copies inside the loop above.
+            while (eqrows) {
+                const int r = __ffsll((unsigned long long)eqrows) - 1;
+                eqrows &= eqrows - 1;
+                const uint2 a = *(const uint2*)(bp + (int64_t)r * rowb);
+                const uint8_t* px = base + ((int64_t)(r0 + r) * W + (int64_t)cg * 16) * 3;
+                unsigned long long nib = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
+#pragma nounroll
+                for (int k = 0; k < 16; ++k, nib >>= 4)
+                    if ((uint32_t)(nib & 15ull) == q && (2125u * px[3 * k] + 7154u * px[3 * k + 1] + 721u * px[3 * k + 2]) >= G_thr)
+                        atomicOr((unsigned long long*)&o[k], 1ull << r);
             }
             return;
         }
