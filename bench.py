@@ -219,8 +219,8 @@ def main():
             # on nothing: they are latency-bound and never dominant)
             npx = H * W
             per_image = {"k_minmax_rgb": npx * 3,                 # image in
-                         "k_hist_rgb": npx * 3 + npx,              # image in, bin plane out (1 byte per pixel)
-                         "k_mask": npx + npx // 8}.get(dominant, img_bytes)   # bin plane in, bit mask out
+                         "k_hist_rgb": npx * 3 + npx // 2,         # image in, class plane out (4 bits per pixel)
+                         "k_mask": npx // 2 + npx // 8}.get(dominant, img_bytes)   # class plane in, bit mask out
             alg_bytes = CH * per_image
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             traffic = None
