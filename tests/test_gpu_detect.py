@@ -261,3 +261,36 @@ def test_dropin_detect_returns_views_equal_to_oracle_crops(golden_dir):
         det.detect_lateral_flow_tests(np.zeros((4, 4, 4, 4), np.uint8))
     with pytest.raises(ValueError):
         det.detect_lateral_flow_tests(np.zeros((8, 8, 4), np.uint8))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_small_images_against_oracle(capi, eng, seed):
+    """Seeded fuzz: random shapes (down to a few pixels), dtypes, blob layouts, thresholds of every kind, line lengths and
+    min_maxr / min_maxc -- every intermediate compared with the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(6):
+        kind = rng.integers(0, 3)                                   # 0: uint8 2-D, 1: uint16 2-D, 2: colour
+        H = int(rng.integers(1, 200)) if rng.random() < 0.8 else int(rng.integers(1, 12))
+        W = int(rng.integers(1, 200)) if rng.random() < 0.8 else int(rng.integers(1, 12))
+        if kind == 2 and rng.random() < 0.5:
+            W = max(16, (W // 16) * 16)                             # the aligned colour path (class plane)
+        top = 255 if kind != 1 else int(rng.choice([255, 4095, 65535]))
+        base = rng.integers(0, max(2, top // 3), size=(H, W))
+        img = base.astype(np.int64)
+        for _b in range(int(rng.integers(0, 6))):                   # bright vertical-ish blobs
+            r0, c0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+            hh, ww = int(rng.integers(1, max(2, H))), int(rng.integers(1, max(2, W // 4 + 1)))
+            img[r0:r0 + hh, c0:c0 + ww] += int(rng.integers(top // 3, top))
+        if rng.random() < 0.3:
+            img[rng.random((H, W)) < 0.02] = top                    # salt
+        img = np.clip(img, 0, top)
+        if kind == 0:
+            arr = img.astype(np.uint8)
+        elif kind == 1:
+            arr = img.astype(np.uint16)
+        else:
+            ch = [np.clip(img + rng.integers(-3, 4, size=(H, W)), 0, 255) for _c in range(3)]
+            arr = np.ascontiguousarray(np.stack(ch, axis=2).astype(np.uint8))
+        L = int(rng.choice([1, 2, 5, 10, 10, 10, 17]))
+        mm_r, mm_c = int(rng.integers(0, max(1, H))), int(rng.integers(0, max(1, W // 2 + 1)))
+        check_detect(capi, eng, arr, mm_r, mm_c, L)

@@ -290,3 +290,46 @@ def test_profile_tables_per_roi_batch(dtype):
         _p, pk2 = eng.profiles(batch, rois, luts=luts, roi_lut=which_bad)
         assert pk2[1]["n_peaks"] == -1 and pk2[0]["n_peaks"] == pk[0]["n_peaks"] and pk2[2]["area"][0] == pk[2]["area"][0]
         eng.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_profiles_peak_logic_against_oracle(seed):
+    """Seeded fuzz of k_peaks: lengths 1..700 (wide peaks cross numpy's 128-term pairwise split), quantised values
+    (ties and plateaus), ramps, both polarities, several window sizes and ranges, single- and two-peak logic."""
+    import warnings
+    import image_analysis_amd._capi as capi
+    rng = np.random.default_rng(500 + seed)
+    eng = capi.shared_engine(0)
+    profs = []
+    for _ in range(60):
+        n = int(rng.integers(1, 700))
+        x = np.arange(n)
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            p = rng.normal(100, 10, n)
+        elif kind == 1:                                             # broad bumps: walks and trapezoid sums of hundreds of terms
+            p = 50 + 80 * np.exp(-0.5 * ((x - rng.uniform(0, n)) / rng.uniform(3, 150)) ** 2) + rng.normal(0, 0.5, n)
+        elif kind == 2:
+            p = np.cumsum(rng.normal(0, 1, n)) + rng.uniform(-50, 50)
+        else:
+            p = rng.integers(0, 4, n).astype(np.float64)            # heavy ties
+        if rng.random() < 0.5:
+            p = np.round(p * 4) / 4
+        profs.append(np.ascontiguousarray(p, dtype=np.float64))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for inverse in (False, True):
+            for window in (25, 3):
+                pk = eng.peaks(profs, inverse=inverse, window_size=window)
+                for i, p in enumerate(profs):
+                    s, e, a = O.analyze_peaks(p, inverse=inverse, window_size=window)
+                    assert (int(pk[i]["start"][0]), int(pk[i]["end"][0])) == (s, e), (seed, i, inverse, window)
+                    assert pk[i]["area"][0] == a or (np.isnan(a) and np.isnan(pk[i]["area"][0])), (seed, i, inverse, window)
+            for r in (15, 1):
+                pk = eng.peaks(profs, inverse=inverse, two_peaks=True, rng=r)
+                for i, p in enumerate(profs):
+                    want = O._two_peaks(p, inverse, r, fallback=not inverse)
+                    assert pk[i]["n_peaks"] == len(want), (seed, i, inverse, r)
+                    for q, (s, e, a) in enumerate(want):
+                        assert (int(pk[i]["start"][q]), int(pk[i]["end"][q])) == (s, e), (seed, i, inverse, r, q)
+                        assert pk[i]["area"][q] == a, (seed, i, inverse, r, q)
