@@ -57,6 +57,39 @@ def bench_u16(B=512, CH=256, pool=8):
     eng.close()
 
 
+def bench_big(B=128, CH=64, pool=4):
+    """configs[3]: 3072x4096 colour images (the reference's phone-camera size), 2 chunk streams like bench.py."""
+    H, W = 3072, 4096
+    pool_np = np.stack([synth.synth_rgb(H, W, 8, 77 + i) for i in range(pool)])
+    p = torch.from_numpy(pool_np.reshape(pool, -1)).to(dev)
+    batch = p[torch.arange(B, device=dev) % pool].contiguous()
+    ms, stride = 16, int(H * .6) + 1
+    mm_c = int(W / 40); mm_r = mm_c * 20
+    engs = [capi.Engine(device=0, max_h=H, max_w=W, max_c=3, max_batch=CH) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    strips = capi.dev_bytes(B * ms * 24, dev); counts = torch.zeros(B, dtype=torch.int32, device=dev)
+    info = capi.dev_bytes(B * 104, dev); rois = capi.dev_bytes(B * ms * 20, dev)
+    prof = torch.empty(B * ms * stride, dtype=torch.float64, device=dev); peaks = capi.dev_bytes(B * ms * 40, dev)
+    ib = H * W * 3
+    torch.cuda.synchronize()
+
+    def step():
+        for ci, b0 in enumerate(range(0, B, CH)):
+            capi._check(capi.lib.lfa_analyze_batch(engs[ci % 2]._h, batch.data_ptr() + b0 * ib, capi.LFA_U8, CH, H, W, 3, mm_r, mm_c, 10,
+                        strips.data_ptr() + b0 * ms * 24, ms, counts.data_ptr() + b0 * 4, info.data_ptr() + b0 * 104,
+                        rois.data_ptr() + b0 * ms * 20, prof.data_ptr() + b0 * ms * stride * 8, stride,
+                        peaks.data_ptr() + b0 * ms * 40, C.c_void_p(streams[ci % 2].cuda_stream)))
+    dt = timed(step)
+    ns = int(counts.sum().item())
+    inf = capi.from_device(info, capi.INFO_DT, B)
+    assert (inf["status"] == 0).all()
+    print(json.dumps({"config": "configs[3] 3072x4096 RGB uint8 images", "images": B, "chunk": CH, "ms_per_step": round(dt * 1e3, 3),
+                      "images_per_s": round(B / dt, 1), "strips_per_s": round(ns / dt, 1), "ambiguous": int(inf["ambiguous"].sum()),
+                      "e2e_frac_hbm": round(B / dt * ib / 8e12, 4)}))
+    for e in engs:
+        e.close()
+
+
 def bench_rois(B=64, per=256):
     H, W = 1536, 2048
     pool_np = np.stack([synth.synth_rgb(H, W, 8, 1234 + i) for i in range(8)])
@@ -139,6 +172,7 @@ def bench_stream(n=512, batch=64, pool=8):
 if __name__ == "__main__":
     what = sys.argv[1:] or ["u16", "rois", "gauss"]
     if "u16" in what: bench_u16()
+    if "big" in what: bench_big()
     if "rois" in what: bench_rois()
     if "gauss" in what: bench_gauss()
     if "peaks" in what: bench_peaks()

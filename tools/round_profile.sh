@@ -12,5 +12,5 @@ cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/round_prof -o r --output-format csv -- python3 $R/bench.py > $R/gpurun_out/round_prof_bench.log 2>&1
 cd $R
 bash tools/pmc_passes.sh > gpurun_out/round_pmc.log 2>&1
-timeout -k 10 300 python benchmarks_configs.py u16 rois gauss peaks > gpurun_out/round_secondary.log 2>&1
+timeout -k 10 300 python benchmarks_configs.py u16 big rois gauss peaks stream > gpurun_out/round_secondary.log 2>&1
 echo done
