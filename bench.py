@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
     ap.add_argument("--chunk", type=int, default=256, help="images per lfa_analyze_batch call")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic images tiled to the batch")
