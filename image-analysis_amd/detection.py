@@ -73,14 +73,14 @@ def straighten_region(copy_image, region, angles):
 
 
 def check_duplicate(minr, minc, maxr, maxc, lst) -> bool:
-    """detection.py:118-127 (host list logic; the batched path runs the same test on the device)."""
-    for region in lst:
-        cur_minr, cur_maxr, cur_minc, cur_maxc = region[0], region[1], region[2], region[3]
-        cur_maxr = max(cur_maxr, cur_minr + min_maxr)
-        cur_maxc = max(cur_maxc, cur_minc + min_maxc)
-        if minr <= cur_maxr and maxr >= cur_minr and minc <= cur_maxc and maxc >= cur_minc:
-            return False
-    return True
+    """True when the box rows [minr, maxr] x cols [minc, maxc] touches none of the regions accepted so far, each of them
+    grown to at least min_maxr x min_maxc; bounds are inclusive (detection.py:118-127).  Host list logic: the batched
+    path runs the same test on the device (k_finalize)."""
+    def grown(reg):
+        r0, r1, c0, c1 = reg[0], reg[1], reg[2], reg[3]
+        return r0, max(r1, r0 + min_maxr), c0, max(c1, c0 + min_maxc)
+
+    return not any(minr <= r1 and maxr >= r0 and minc <= c1 and maxc >= c0 for r0, r1, c0, c1 in map(grown, lst))
 
 
 def remove_outliers(lst):
