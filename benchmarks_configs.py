@@ -154,7 +154,7 @@ def bench_peaks(n=16384, length=288):
     eng.close()
 
 
-def bench_stream(n=512, batch=64, pool=8):
+def bench_stream(n=1024, batch=64, pool=8):
     """PCIe-inclusive rate: frames start in pageable host memory (numpy), frames.analyze_stream packs them into pinned
     batches, uploads and analyses them double-buffered.  Never the headline number (bench.py's `value` has inputs in HBM)."""
     from image_analysis_amd import frames as F

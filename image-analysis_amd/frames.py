@@ -65,7 +65,7 @@ def imread(path) -> np.ndarray:
     return np.ascontiguousarray(a[:, :, ::-1])
 
 
-def analyze_stream(frames, batch=16, device=0, line_length=10, max_strips=64, min_maxr=None, min_maxc=None, pack_threads=8):
+def analyze_stream(frames, batch=16, device=0, line_length=10, max_strips=64, min_maxr=None, min_maxc=None, pack_threads=16):
     """detect + image_analysis(strip, False) for every frame of an iterable of equally shaped uint8/uint16 frames.
 
     Yields, in input order, one `(frame_index, strips, profiles, peaks)` per frame: `strips` a STRIP_DT array, `profiles`
