@@ -620,7 +620,23 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
         const dim3 grid(blocks_per_image(j, 256 * 64), j.n);
         LFA_DISPATCH_V(k_minmax_rgb, grid, dim3(256), s, j);
         LFA_LAUNCH("k_edges_rgb", k_edges_rgb, dim3(j.n), dim3(320), 0, s, j);
-        LFA_DISPATCH_V(k_hist_rgb, grid, dim3(256), s, j);
+        {
+            // the histogram blocks live for the whole launch (grid-stride), so the grid is sized to whole rounds of
+            // what the chip holds at once: 4096 blocks on a capacity of 1280 would run 3.2 rounds, i.e. pay for 4
+            static const int capacity = [] {
+                int per_cu = 0, dev = 0;
+                hipDeviceProp_t prop;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_hist_rgb<0>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+                if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1024;
+                return per_cu * prop.multiProcessorCount;
+            }();
+            int per_image = (3 * capacity + j.n / 2) / j.n;
+            const int need = (int)(((int64_t)j.H * j.W + 256 * 64 - 1) / (256 * 64));
+            if (per_image > need) per_image = need;
+            if (per_image < 1) per_image = 1;
+            const dim3 gridh(per_image, j.n);
+            LFA_DISPATCH_V(k_hist_rgb, gridh, dim3(256), s, j);
+        }
         LFA_LAUNCH("k_otsu_rgb", k_otsu_rgb, dim3(j.n), dim3(256), 0, s, j);
     } else if (j.dtype == LFA_U8) {
         const dim3 grid(blocks_per_image(j, 256 * 128), j.n);
