@@ -94,6 +94,16 @@ int main() {
                    (double)(in_bytes + ngroups * 16) * reps / (ms * 1e6));
         }
     }
+    {
+        const size_t n = (size_t)2048 << 20;                         // hipMemcpy device to device, 2 GiB (read + write counted)
+        for (int w = 0; w < 2; ++w) CK(hipMemcpyAsync(buf + n, buf, n, hipMemcpyDeviceToDevice, s));
+        CK(hipEventRecord(e0, s));
+        const int reps = 10;
+        for (int r = 0; r < reps; ++r) CK(hipMemcpyAsync(buf + n, buf, n, hipMemcpyDeviceToDevice, s));
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("hipMemcpyD2D_read_plus_write,%zu,%.4f,%.1f\n", (2 * n) >> 20, ms / reps, (double)2 * n * reps / (ms * 1e6));
+    }
     CK(hipGetLastError());
     return 0;
 }
