@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=64, help="images for the one-core CPU baseline (0 = skip); the pool run takes 8x as many")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU pool baseline (0 = min(16, cpu_count))")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (one LfaHandle each) the chunks alternate on")
+    ap.add_argument("--stagger", type=int, default=0, help="1: a chunk's image passes start when the previous chunk's histogram pass is done")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
@@ -141,6 +142,8 @@ def main():
             nb = min(CH, B - b0)
             e = engs[ci % ns]
             stream = ctypes.c_void_p(streams[ci % ns].cuda_stream)
+            if ns > 1 and args.stagger:
+                capi._check(capi.lib.lfa_stream_wait_passes(engs[(ci - 1) % ns]._h, stream))
             capi._check(capi.lib.lfa_analyze_batch(
                 e._h, batch.data_ptr() + b0 * img_bytes, capi.LFA_U8, nb, H, W, C, mm_r, mm_c, 10,
                 strips.data_ptr() + b0 * max_strips * capi.STRIP_DT.itemsize, max_strips,

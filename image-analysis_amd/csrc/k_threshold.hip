@@ -637,10 +637,12 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
             const dim3 gridh(per_image, j.n);
             LFA_DISPATCH_V(k_hist_rgb, gridh, dim3(256), s, j);
         }
+        if (j.passes_event) (void)hipEventRecord(j.passes_event, s);
         LFA_LAUNCH("k_otsu_rgb", k_otsu_rgb, dim3(j.n), dim3(256), 0, s, j);
     } else if (j.dtype == LFA_U8) {
         const dim3 grid(blocks_per_image(j, 256 * 128), j.n);
         LFA_LAUNCH("k_hist_u8", k_hist_u8, grid, dim3(256), 0, s, j);
+        if (j.passes_event) (void)hipEventRecord(j.passes_event, s);
         LFA_LAUNCH("k_otsu_int", k_otsu_int, dim3(j.n), dim3(256), 0, s, j);
     } else {
         const dim3 grid(blocks_per_image(j, 256 * 64), j.n);
@@ -648,6 +650,7 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
         LFA_LAUNCH("k_zero_hist_u16", k_zero_hist_u16, dim3(16, j.n), dim3(256), 0, s, j);
         const dim3 gridh(blocks_per_image(j, 1024 * 64), j.n);
         LFA_LAUNCH("k_hist_u16", k_hist_u16, gridh, dim3(1024), 0, s, j);
+        if (j.passes_event) (void)hipEventRecord(j.passes_event, s);
         LFA_LAUNCH("k_otsu_int", k_otsu_int, dim3(j.n), dim3(256), 0, s, j);
     }
     return hipGetLastError();

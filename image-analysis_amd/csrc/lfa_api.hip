@@ -97,6 +97,7 @@ struct LfaContext {
     lfa::Job last{};
     bool have_last = false;
     EventTimer* timer = nullptr;
+    hipEvent_t passes_event = nullptr;     // see lfa_stream_wait_passes
     std::vector<Buf*> all() {
         return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_tmp, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
                 &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &lut8, &lut16, &rois};
@@ -200,6 +201,7 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.edges_g = (double*)h->edges.p;
     j.edges_i = (uint32_t*)h->edges_i.p;
     // bin plane: colour images on the vector paths only (16-pixel groups in k_hist_rgb, 16-column groups in k_mask)
+    j.passes_event = h->passes_event;
     j.bins = (C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2)) ? (uint8_t*)h->bins.p : nullptr;
     j.maskT = (uint64_t*)h->maskT.p;
     j.col_cnt = (uint32_t*)h->col_cnt.p;
@@ -292,6 +294,10 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         return fail(LFA_ERR_HIP, "uploading gamma tables failed");
     }
     if ((rc = ensure_workspace(h, max_batch, max_h, max_w, max_c, LFA_U16, 10, 64))) { lfa_destroy(h); return rc; }
+    if (hipEventCreateWithFlags(&h->passes_event, hipEventDisableTiming) != hipSuccess) {
+        h->passes_event = nullptr; lfa_destroy(h);
+        return fail(LFA_ERR_HIP, "hipEventCreate failed");
+    }
     *out = h;
     return LFA_OK;
 }
@@ -300,6 +306,7 @@ int lfa_destroy(LfaHandle h) {
     if (!h) return LFA_OK;
     DeviceGuard guard_(h->device);
     for (Buf* b : h->all()) if (b->p) (void)hipFree(b->p);
+    if (h->passes_event) (void)hipEventDestroy(h->passes_event);
     delete h->timer;
     delete h;
     return LFA_OK;
@@ -498,6 +505,13 @@ int lfa_timing_read(LfaHandle h, int max_entries, char* names, double* total_ms,
     }
     t->recs.clear();
     *n_out = n;
+    return LFA_OK;
+}
+
+int lfa_stream_wait_passes(LfaHandle producer, void* stream) {
+    if (!producer) return fail(LFA_ERR_ARG, "null handle");
+    LFA_ON_DEVICE(producer->device);
+    LFA_HIP(hipStreamWaitEvent((hipStream_t)stream, producer->passes_event, 0));
     return LFA_OK;
 }
 

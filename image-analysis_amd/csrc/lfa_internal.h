@@ -42,6 +42,7 @@ struct Job {
     double* otsu_s;          // [n][2][hist_stride]  the matching cumsum(counts*centers) arrays
     double* edges_g;         // [n][257]  gray-space bin edges (colour path)
     uint32_t* edges_i;       // [n][264]  the same as integer thresholds on G = 2125*b0 + 7154*b1 + 721*b2 (k_threshold.hip)
+    hipEvent_t passes_event; // recorded on the launch stream right after the histogram pass (lfa_stream_wait_passes); may be null
     uint8_t* bins;           // [n][H*W/2]  colour path: class plane, (histogram bin >> 4) of every pixel in 4 bits, written by
                              //             k_hist_rgb and read by k_mask instead of the image (0.5 byte per pixel instead of 3);
                              //             null = not used

@@ -216,6 +216,14 @@ int lfa_debug_fetch(LfaHandle h, int image_index, int what, void* out, int64_t o
 int lfa_timing_enable(LfaHandle h, const char* kernel_filter);
 int lfa_timing_read(LfaHandle h, int max_entries, char* names, double* total_ms, int32_t* launches, int32_t* n_out);
 
+/* Chunk pipelining over two handles (no counterpart in the reference).  Every detect/analyze call records an event on
+ * its stream right after its histogram pass, i.e. when two of its three whole-image passes are done and what is left
+ * is the (short) mask pass and the latency-bound tail (labelling, regions, profiles, peaks).  lfa_stream_wait_passes
+ * makes `stream` wait for that point of `producer`'s most recent call (no-op before its first call), so a caller that
+ * feeds consecutive batches to two handles on two streams can start batch k+1's passes when batch k stops needing
+ * the memory bandwidth, and batch k's tail runs in their shadow. */
+int lfa_stream_wait_passes(LfaHandle producer, void* stream);
+
 /* Block until everything enqueued on `stream` through this handle has finished. */
 int lfa_sync(LfaHandle h, void* stream);
 
