@@ -97,3 +97,49 @@ def test_batch_properties_and_determinism():
         want = O.detect_debug(flipped[k], mm_r, mm_c)["strips"]
         assert _strips(rf[k][0]) == want
     eng.close()
+
+
+def test_two_handles_chained_with_stream_wait_passes():
+    """Chunks alternating on two handles / streams, each chunk's passes chained to the previous chunk's histogram pass
+    (lfa_stream_wait_passes): same strips, profiles and peaks as one handle processing the chunks one after the other."""
+    import ctypes as C
+    import torch
+    import image_analysis_amd._capi as capi
+    from image_analysis_amd.synth import synth_rgb
+    H, W, n, ch = 384, 512, 12, 3
+    imgs = np.stack([synth_rgb(H, W, 6, 900 + i) for i in range(n)])
+    mm_c = int(W / 40); mm_r = mm_c * 20
+    ref_eng = capi.Engine(device=0, max_h=H, max_w=W, max_batch=ch)
+    want, _ = ref_eng.analyze(imgs, mm_r, mm_c, max_strips=16)
+    ref_eng.close()
+    dev = torch.device("cuda", 0)
+    engs = [capi.Engine(device=0, max_h=H, max_w=W, max_batch=ch) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    batch = capi.to_device(imgs, dev)
+    ms, stride = 16, int(H * .6) + 1
+    strips = capi.dev_bytes(n * ms * 24, dev); counts = torch.zeros(n, dtype=torch.int32, device=dev)
+    info = capi.dev_bytes(n * 104, dev); rois = capi.dev_bytes(n * ms * 20, dev)
+    prof = torch.zeros(n * ms * stride, dtype=torch.float64, device=dev); peaks = capi.dev_bytes(n * ms * 40, dev)
+    torch.cuda.synchronize()
+    ib = H * W * 3
+    for rep in range(2):
+        for ci, b0 in enumerate(range(0, n, ch)):
+            st = C.c_void_p(streams[ci % 2].cuda_stream)
+            capi._check(capi.lib.lfa_stream_wait_passes(engs[(ci - 1) % 2]._h, st))
+            capi._check(capi.lib.lfa_analyze_batch(engs[ci % 2]._h, batch.data_ptr() + b0 * ib, capi.LFA_U8, ch, H, W, 3, mm_r, mm_c, 10,
+                        strips.data_ptr() + b0 * ms * 24, ms, counts.data_ptr() + b0 * 4, info.data_ptr() + b0 * 104,
+                        rois.data_ptr() + b0 * ms * 20, prof.data_ptr() + b0 * ms * stride * 8, stride,
+                        peaks.data_ptr() + b0 * ms * 40, st))
+    torch.cuda.synchronize()
+    cn = counts.cpu().numpy()
+    st_np = capi.from_device(strips, capi.STRIP_DT, n * ms).reshape(n, ms)
+    pk_np = capi.from_device(peaks, capi.PEAKS_DT, n * ms).reshape(n, ms)
+    pr_np = prof.cpu().numpy().reshape(n, ms, stride)
+    for i in range(n):
+        w_strips, w_profiles, w_peaks = want[i]
+        assert cn[i] == len(w_strips) and np.array_equal(st_np[i, :cn[i]], w_strips)
+        for k in range(cn[i]):
+            assert np.array_equal(pr_np[i, k, :pk_np[i, k]["length"]], w_profiles[k])
+            assert pk_np[i, k] == w_peaks[k]
+    for e in engs:
+        e.close()
