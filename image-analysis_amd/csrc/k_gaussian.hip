@@ -7,29 +7,30 @@
 // correlate1d's symmetric-kernel loop (scipy/ndimage/src/ni_filters.c, not vendored as source in the reference tree)
 // is restated as: tmp = x[0]*w[R]; for k = R..1: tmp += (x[-k] + x[+k]) * w[R-k]  -- no fused multiply-add.
 //
-// One 256-thread block stages 16 rows x 256 element columns and outputs the inner 256 - 2*R*C of them (a row of a colour image is W*3 elements with horizontal
-// taps 3 apart).  Vertical pass: every thread owns one element column, walks down the tile's rows (+R halo rows above
+// One block stages 8 rows x kIW element columns (512 for colour, 256 for grey images), one column per thread, and outputs
+// the inner kIW - 2*R*C of them (a row of a colour image is W*3 elements with horizontal taps 3 apart).  Vertical pass: every thread owns one element column, walks down the tile's rows (+R halo rows above
 // and below) reading the image coalesced, and keeps the 2R+1 most recent float64 values in registers (sliding
 // window), so each input byte is read once and no input staging is needed; results go to LDS (float64).  Horizontal
 // pass: every thread owns one output column and reads its 2R+1 taps from LDS (stride-1 across lanes: conflict-free),
-// writing whole rows (2 KiB per wave).  The kernel is bound by the float64 output stream (8 bytes out per byte in).
+// writing whole rows (512 B per wave and row).  Where the time goes (PMC + ablations): the float64
+// output stream (8 bytes out per byte in) and 30 float64 operations per output that the reference's rounding order does
+// not let fuse; the two overlap only partly.
 #include "lfa_internal.h"
 #include "lfa_device.h"
 
 namespace lfa {
 
-constexpr int kTH = 16, kIW = 256;    // tile: rows x staged element columns (output columns = kIW - 2*R*C)
-
 struct GaussW { double w[2 * kGaussMaxRadius + 1]; int radius; };
 
-template <typename PIX, typename OUT, int R>
-__global__ __launch_bounds__(256) void k_gaussian(Job j, GaussW gw, OUT* out) {
+// tile: kTH rows x kIW staged element columns, one column per thread (output columns = kIW - 2*R*C).  C (1 or 3) is a
+// template parameter so that the horizontal taps are immediate offsets of the LDS reads.
+template <typename PIX, typename OUT, int C, int R, int kTH, int kIW>
+__global__ __launch_bounds__(kIW) void k_gaussian(Job j, GaussW gw, OUT* out) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int C = j.C;
-    const int hal = R * C;                       // horizontal halo in elements
-    const int IW = kIW;                          // columns the vertical pass produces: exactly one per thread
-    const int kTE = kIW - 2 * hal;               // output columns of the tile
-    double* vres = (double*)smem;                // [kTH][IW]
+    constexpr int hal = R * C;                   // horizontal halo in elements
+    constexpr int kTE = kIW - 2 * hal;           // output columns of the tile
+    static_assert(kTE > 0, "tile narrower than the halo");
+    double* vres = (double*)smem;                // [kTH][kIW]
     const int img = blockIdx.z;
     const PIX* base = (const PIX*)(j.images + (int64_t)img * j.img_bytes);
     const int E = j.W * C;
@@ -42,18 +43,17 @@ __global__ __launch_bounds__(256) void k_gaussian(Job j, GaussW gw, OUT* out) {
 
     // ---- vertical pass (axis 0): thread t owns staged column t
     {
-        const int ee = t;
-        const int e = e0 + ee - hal;                              // may be outside [0,E): 'nearest' border per channel
-        int px = (e >= 0 ? e / C : -((-e + C - 1) / C));
-        const int ch = e - px * C;
-        px = px < 0 ? 0 : (px >= j.W ? j.W - 1 : px);
+        const uint32_t eh = (uint32_t)(e0 + t);                   // element + hal: never negative
+        int px = (int)(eh / (uint32_t)C) - R;                     // 'nearest' border, per channel
+        const int ch = (int)(eh % (uint32_t)C);
+        px = min(max(px, 0), j.W - 1);
         const PIX* col = base + px * C + ch;
         // all kTH + 2R rows of this column are requested before the first is used (one memory latency per tile, not one
         // per row); the tile height is a compile-time constant, so `raw` and the window stay in registers
         PIX raw[kTH + 2 * R];
 #pragma unroll
         for (int k = 0; k < kTH + 2 * R; ++k) {
-            int r = r0 - R + k; r = r < 0 ? 0 : (r >= j.H ? j.H - 1 : r);
+            const int r = min(max(r0 - R + k, 0), j.H - 1);
             raw[k] = col[(int64_t)r * E];
         }
         double win[2 * R + 1];
@@ -67,11 +67,12 @@ __global__ __launch_bounds__(256) void k_gaussian(Job j, GaussW gw, OUT* out) {
             double tmp = win[R] * w[R];
 #pragma unroll
             for (int q = R; q >= 1; --q) tmp = tmp + (win[R - q] + win[R + q]) * w[R - q];
-            vres[rr * IW + ee] = tmp;
+            vres[rr * kIW + t] = tmp;
         }
     }
     __syncthreads();
-    // ---- horizontal pass (axis 1)
+    // ---- horizontal pass (axis 1): thread t owns output column t of the tile.  The float64 result is written once and
+    // never read again by this kernel: nontemporal stores (measured +3..5 % on this write-dominated stream).
     const int e = e0 + t;
     if (t < kTE && e < E) {
         const double* rowp = vres + hal + t;
@@ -79,31 +80,52 @@ __global__ __launch_bounds__(256) void k_gaussian(Job j, GaussW gw, OUT* out) {
 #pragma unroll
         for (int rr = 0; rr < kTH; ++rr) {
             if (r0 + rr >= j.H) break;
-            const double* row = rowp + rr * IW;
+            const double* row = rowp + rr * kIW;
             double tmp = row[0] * w[R];
 #pragma unroll
             for (int q = R; q >= 1; --q) tmp = tmp + (row[-q * C] + row[q * C]) * w[R - q];
-            o[(int64_t)rr * E] = (OUT)tmp;
+            __builtin_nontemporal_store((OUT)tmp, o + (int64_t)rr * E);
         }
     }
 }
 
-template <typename PIX, typename OUT>
-static void launch_r(const Job& j, const GaussW& gw, OUT* out, hipStream_t s) {
-    const int E = j.W * j.C;
-    const int te = kIW - 2 * gw.radius * j.C;
+template <typename PIX, typename OUT, int C, int R, int kTH, int kIW>
+static hipError_t launch_t(const Job& j, const GaussW& gw, OUT* out, hipStream_t s) {
+    const int E = j.W * C;
+    constexpr int te = kIW - 2 * R * C;
     const size_t lds = (size_t)kTH * kIW * sizeof(double);
     const dim3 grid((E + te - 1) / te, (j.H + kTH - 1) / kTH, j.n);
+    if (grid.y > 65535 || grid.z > 65535) return hipErrorInvalidValue;
+    LFA_LAUNCH("k_gaussian", (k_gaussian<PIX, OUT, C, R, kTH, kIW>), grid, dim3(kIW), lds, s, j, gw, out);
+    return hipSuccess;
+}
+
+// tile shapes from the sweep in DESIGN.md section 4 (sigma 1): 8 x 512 for colour rows (halo 24 of 512 columns),
+// 8 x 256 for grey rows
+template <typename PIX, typename OUT, int C, int R>
+static hipError_t launch_shape(const Job& j, const GaussW& gw, OUT* out, hipStream_t s) {
+    if (C == 3) return launch_t<PIX, OUT, C, R, 8, 512>(j, gw, out, s);
+    return launch_t<PIX, OUT, C, R, 8, 256>(j, gw, out, s);
+}
+
+template <typename PIX, typename OUT, int C>
+static hipError_t launch_r(const Job& j, const GaussW& gw, OUT* out, hipStream_t s) {
     switch (gw.radius) {
-        case 1: LFA_LAUNCH("k_gaussian", (k_gaussian<PIX, OUT, 1>), grid, dim3(256), lds, s, j, gw, out); break;
-        case 2: LFA_LAUNCH("k_gaussian", (k_gaussian<PIX, OUT, 2>), grid, dim3(256), lds, s, j, gw, out); break;
-        case 3: LFA_LAUNCH("k_gaussian", (k_gaussian<PIX, OUT, 3>), grid, dim3(256), lds, s, j, gw, out); break;
-        case 4: LFA_LAUNCH("k_gaussian", (k_gaussian<PIX, OUT, 4>), grid, dim3(256), lds, s, j, gw, out); break;
-        case 5: LFA_LAUNCH("k_gaussian", (k_gaussian<PIX, OUT, 5>), grid, dim3(256), lds, s, j, gw, out); break;
-        case 6: LFA_LAUNCH("k_gaussian", (k_gaussian<PIX, OUT, 6>), grid, dim3(256), lds, s, j, gw, out); break;
-        case 7: LFA_LAUNCH("k_gaussian", (k_gaussian<PIX, OUT, 7>), grid, dim3(256), lds, s, j, gw, out); break;
-        default: LFA_LAUNCH("k_gaussian", (k_gaussian<PIX, OUT, 8>), grid, dim3(256), lds, s, j, gw, out); break;
+        case 1: return launch_shape<PIX, OUT, C, 1>(j, gw, out, s);
+        case 2: return launch_shape<PIX, OUT, C, 2>(j, gw, out, s);
+        case 3: return launch_shape<PIX, OUT, C, 3>(j, gw, out, s);
+        case 4: return launch_shape<PIX, OUT, C, 4>(j, gw, out, s);
+        case 5: return launch_shape<PIX, OUT, C, 5>(j, gw, out, s);
+        case 6: return launch_shape<PIX, OUT, C, 6>(j, gw, out, s);
+        case 7: return launch_shape<PIX, OUT, C, 7>(j, gw, out, s);
+        default: return launch_shape<PIX, OUT, C, 8>(j, gw, out, s);
     }
+}
+
+template <typename OUT>
+static hipError_t launch_o(const Job& j, const GaussW& gw, OUT* out, hipStream_t s) {
+    if (j.dtype == LFA_U8) return j.C == 3 ? launch_r<uint8_t, OUT, 3>(j, gw, out, s) : launch_r<uint8_t, OUT, 1>(j, gw, out, s);
+    return launch_r<uint16_t, OUT, 1>(j, gw, out, s);
 }
 
 hipError_t launch_gaussian_w(const Job& j, const double* w, int radius, void* out, int out_f32, hipStream_t s) {
@@ -111,14 +133,9 @@ hipError_t launch_gaussian_w(const Job& j, const double* w, int radius, void* ou
     GaussW gw;
     gw.radius = radius;
     for (int k = 0; k < 2 * radius + 1; ++k) gw.w[k] = w[k];
-    if (j.dtype == LFA_U8) {
-        if (out_f32) launch_r<uint8_t, float>(j, gw, (float*)out, s);
-        else         launch_r<uint8_t, double>(j, gw, (double*)out, s);
-    } else {
-        if (out_f32) launch_r<uint16_t, float>(j, gw, (float*)out, s);
-        else         launch_r<uint16_t, double>(j, gw, (double*)out, s);
-    }
-    return hipGetLastError();
+    if (j.C != 1 && !(j.C == 3 && j.dtype == LFA_U8)) return hipErrorInvalidValue;
+    const hipError_t e = out_f32 ? launch_o<float>(j, gw, (float*)out, s) : launch_o<double>(j, gw, (double*)out, s);
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 }  // namespace lfa

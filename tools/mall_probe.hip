@@ -35,6 +35,32 @@ __global__ __launch_bounds__(256) void k_read3_write1(const uint4* p, uint4* q, 
     }
 }
 
+// the Gaussian stage's traffic shape: 1 byte in, 8 bytes out per element (u8 -> f64), and write-only
+__global__ __launch_bounds__(256) void k_read1_write8(const uint32_t* p, double* q, size_t n4) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    // lane handles 4 consecutive bytes per step but writes them as 4 row-strided stores so that a wave's store is contiguous
+    for (size_t base = (size_t)blockIdx.x * 1024; base < n4 * 4; base += (size_t)gridDim.x * 1024) {
+        const uint8_t* pb = (const uint8_t*)p + base;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t e = base + k * 256 + threadIdx.x;
+            q[e] = (double)pb[k * 256 + threadIdx.x] * (1.0 / 255.0);
+        }
+    }
+    (void)g; (void)step;
+}
+__global__ __launch_bounds__(256) void k_write8(double* q, size_t n) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; g < n; g += step) q[g] = (double)g;
+}
+__global__ __launch_bounds__(256) void k_write16(double2* q, size_t n) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; g < n; g += step) q[g] = make_double2((double)g, 1.0);
+}
+
 static int grid_for(size_t n16) {
     size_t blocks = (n16 + 256 * 8 - 1) / (256 * 8);      // about 8 x 16 bytes per lane
     if (blocks > 256 * 16) blocks = 256 * 16;
@@ -103,6 +129,40 @@ int main() {
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("hipMemcpyD2D_read_plus_write,%zu,%.4f,%.1f\n", (2 * n) >> 20, ms / reps, (double)2 * n * reps / (ms * 1e6));
+    }
+    {
+        const size_t n_in = (size_t)384 << 20;                       // 384 MiB of bytes in, 3 GiB of doubles out
+        double* q = (double*)(buf + ((size_t)512 << 20));
+        for (int blocks : {2048, 4096, 8192, 16384}) {
+            for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_read1_write8, dim3(blocks), dim3(256), 0, s, (const uint32_t*)buf, q, n_in / 4);
+            CK(hipEventRecord(e0, s));
+            const int reps = 10;
+            for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_read1_write8, dim3(blocks), dim3(256), 0, s, (const uint32_t*)buf, q, n_in / 4);
+            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("read1_write8_blocks%d,%zu,%.4f,%.1f\n", blocks, (n_in * 9) >> 20, ms / reps, (double)n_in * 9 * reps / (ms * 1e6));
+        }
+        const size_t n = ((size_t)3072 << 20) / 8;
+        for (int blocks : {2048, 8192}) {
+            for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_write8, dim3(blocks), dim3(256), 0, s, q, n);
+            CK(hipEventRecord(e0, s));
+            const int reps = 10;
+            for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_write8, dim3(blocks), dim3(256), 0, s, q, n);
+            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("write8_blocks%d,%zu,%.4f,%.1f\n", blocks, (n * 8) >> 20, ms / reps, (double)n * 8 * reps / (ms * 1e6));
+            for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_write16, dim3(blocks), dim3(256), 0, s, (double2*)q, n / 2);
+            CK(hipEventRecord(e0, s));
+            for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_write16, dim3(blocks), dim3(256), 0, s, (double2*)q, n / 2);
+            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("write16_blocks%d,%zu,%.4f,%.1f\n", blocks, (n * 8) >> 20, ms / reps, (double)n * 8 * reps / (ms * 1e6));
+        }
+        CK(hipEventRecord(e0, s));
+        for (int r = 0; r < 10; ++r) CK(hipMemsetAsync(q, 0, n * 8, s));
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("hipMemset,%zu,%.4f,%.1f\n", (n * 8) >> 20, ms / 10, (double)n * 8 * 10 / (ms * 1e6));
     }
     CK(hipGetLastError());
     return 0;
