@@ -13,6 +13,7 @@
 #include "lfa_internal.h"
 #include "lfa_algo.h"
 #include "lfa_device.h"
+#include <type_traits>
 
 namespace lfa {
 
@@ -363,21 +364,36 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     if (integer_path) {
         if (j.aligned16) {
             const int64_t ng = npix >> 4;
-            for (int64_t g = tid; g < ng; g += nth) {
-                uint32_t w[12];
-                load48(base + g * 48, w);
-                uint32_t G[16], kb[16], flags = 0;
+            // The next group's 48 bytes are requested before this group's ~500 instructions start, so a wave never
+            // stands still for a memory latency; the class-plane store of a round stays in flight across the loop
+            // boundary (lfa_device.h, "vector memory operations issued by hand").  The last round asks for its own
+            // group again; the copy is not used.
+            auto pass = [&](auto plane) {
+                constexpr bool kPlane = decltype(plane)::value;
+                Raw48 nx;
+                int64_t g = tid;
+                if (g >= ng) return;
+                vm_request48(base + g * 48, nx);
+                vm_wait48<0>(nx);
+                for (; g < ng; g += nth) {
+                    uint32_t w[12];
+                    unpack48(nx, w);
+                    vm_request48(base + (g + nth < ng ? g + nth : g) * 48, nx);
+                    uint32_t G[16], kb[16], flags = 0;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) { G[k] = gray_G16(w, k); kb[k] = binG(G[k], flags); }
-                if ((int)flags < 0) {                                 // some pixel of the group is in a two-edge bucket
+                    for (int k = 0; k < 16; ++k) { G[k] = gray_G16(w, k); kb[k] = binG(G[k], flags); }
+                    if ((int)flags < 0) {                             // some pixel of the group is in a two-edge bucket
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) kb[k] = walk(G[k], kb[k]);
+                        for (int k = 0; k < 16; ++k) kb[k] = walk(G[k], kb[k]);
+                    }
+                    uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) { hadd(kb[k]); pk[k >> 3] |= (kb[k] >> 4) << (4 * (k & 7)); }
+                    if (kPlane) vm_store8(bins + g * 8, pk[0], pk[1]);
+                    vm_wait48<kPlane ? 1 : 0>(nx);                    // the requested bytes are in; this round's store may still be on its way
                 }
-                uint32_t pk[2] = {0u, 0u};
-#pragma unroll
-                for (int k = 0; k < 16; ++k) { hadd(kb[k]); pk[k >> 3] |= (kb[k] >> 4) << (4 * (k & 7)); }
-                if (bins) *(uint2*)(bins + g * 8) = make_uint2(pk[0], pk[1]);
-            }
+            };
+            if (bins) pass(std::true_type{}); else pass(std::false_type{});
             done = ng << 4;
         }
         for (int64_t p = done + tid; p < npix; p += nth) {

@@ -51,6 +51,35 @@ __device__ inline void load48(const uint8_t* p, uint32_t (&w)[12]) {
     w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
 }
 
+// ---- vector memory operations issued by hand (prefetch loops)
+// gfx950 counts loads and stores of a wave in ONE in-order counter (vmcnt).  A loop that requests the next group's bytes
+// before it works on this group's, and stores a result per round, needs "wait until the prefetched bytes are in" =
+// "wait until at most <stores issued after them> operations are outstanding".  The compiler only proves that count in
+// straight-line code and waits for everything (the store's round trip included) at a loop boundary, so these loops
+// issue their loads, their store and the wait themselves and keep the number of operations per round a constant.
+typedef uint32_t lfa_u32x4 __attribute__((ext_vector_type(4)));
+struct Raw48 { lfa_u32x4 a, b, c; };
+__device__ __forceinline__ void vm_request48(const uint8_t* p, Raw48& r) {                    // 3 operations
+    asm volatile("global_load_dwordx4 %0, %3, off\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32"
+                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c) : "v"(p));
+}
+__device__ __forceinline__ void vm_store8(void* p, uint32_t lo, uint32_t hi) {                // 1 operation
+    const uint2 v = make_uint2(lo, hi);
+    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+template <int LEFT>   // wait until at most LEFT vector memory operations of this wave are outstanding, then release r
+__device__ __forceinline__ void vm_wait48(Raw48& r) {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LEFT) : "memory");
+    asm volatile("" : "+v"(r.a), "+v"(r.b), "+v"(r.c));
+}
+__device__ __forceinline__ void unpack48(const Raw48& r, uint32_t (&w)[12]) {
+    w[0] = r.a.x; w[1] = r.a.y; w[2] = r.a.z; w[3] = r.a.w;
+    w[4] = r.b.x; w[5] = r.b.y; w[6] = r.b.z; w[7] = r.b.w;
+    w[8] = r.c.x; w[9] = r.c.y; w[10] = r.c.z; w[11] = r.c.w;
+}
+
 // byte k of a little-endian dword array; k must be a compile-time constant after unrolling
 template <int N>
 __device__ inline uint32_t byte_of(const uint32_t (&w)[N], int k) {
