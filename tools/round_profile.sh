@@ -12,5 +12,10 @@ cd /tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/round_prof -o r --output-format csv -- python3 $R/bench.py > $R/gpurun_out/round_prof_bench.log 2>&1
 cd $R
 bash tools/pmc_passes.sh > gpurun_out/round_pmc.log 2>&1
-timeout -k 10 300 python benchmarks_configs.py u16 big rois gauss peaks stream > gpurun_out/round_secondary.log 2>&1
+# one process per configuration: measured in one process after another configuration, configs[3] came out 14 % lower
+# (allocator / placement state left behind), alone it repeats within 0.3 %
+: > gpurun_out/round_secondary.log
+for c in u16 big rois gauss peaks stream; do
+  timeout -k 10 200 python benchmarks_configs.py $c >> gpurun_out/round_secondary.log 2>&1
+done
 echo done
