@@ -110,10 +110,12 @@ def bench_rois(B=64, per=256):
         capi._check(capi.lib.lfa_profile_batch(eng._h, batch.data_ptr(), capi.LFA_U8, B, H, W, 3, rt.data_ptr(), n, 0, 15,
                                                prof.data_ptr(), stride, peaks.data_ptr(), st))
     dt = timed(step)
+    eng.timing("*"); step(); torch.cuda.synchronize(); kt = eng.timing_read(); eng.timing(None)
     byts = int(((rois["r1"] - rois["r0"]).astype(np.int64) * (rois["c1"] - rois["c0"]) * 3).sum())
     print(json.dumps({"config": "configs[4] dense select-region: 256 ROIs/image", "images": B, "rois": n,
                       "ms_per_step": round(dt * 1e3, 3), "rois_per_s": round(n / dt, 1), "window_bytes": byts,
-                      "GBps_algorithmic": round(byts / dt / 1e9, 1), "frac_hbm": round(byts / dt / 8e12, 4)}))
+                      "GBps_algorithmic": round(byts / dt / 1e9, 1), "frac_hbm": round(byts / dt / 8e12, 4),
+                      "kernel_ms": {k: round(v[0], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}}))
     eng.close()
 
 

@@ -168,11 +168,26 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
             const int items = len * nch;
             const int qg = G / nch, mg = G - qg * nch;                         // (row, piece) advance by G items without a division
             int r = lg / nch, d = lg - r * nch;
-            for (int it0 = lg; it0 < items; it0 += G * 4) {
-                uint4 x[4];
-                int rr[4], dd[4];
+            // Only the first and the last piece of a row reach outside the window: their byte masks are the same on
+            // every row, so they are built once per ROI (first: bytes before b0 off; last: bytes from b0 + nbytes on off)
+            // and an item costs two selects, an AND and a v_sad_u8 per dword.
+            uint32_t mfirst[4], mlast[4];
+            {
+                const int lo = (int)(b0 - a0);                                 // 0..15 bytes to drop at the front of piece 0
+                const int hi = (int)(b0 + nbytes - (a0 + 16 * (int64_t)(nch - 1)));   // 1..16 bytes to keep of the last piece
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int k = 0; k < 4; ++k) {
+                    const int l = min(max(lo - 4 * k, 0), 4), h = min(max(hi - 4 * k, 0), 4);
+                    mfirst[k] = l >= 4 ? 0u : (0xffffffffu << (8 * l));
+                    mlast[k] = h >= 4 ? 0xffffffffu : ~(0xffffffffu << (8 * h));
+                }
+            }
+            constexpr int U = LUT ? 4 : 8;                                     // loads in flight per lane
+            for (int it0 = lg; it0 < items; it0 += G * U) {
+                uint4 x[U];
+                int rr[U], dd[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
                     rr[u] = r; dd[u] = d;
                     if (it0 + G * u < items) x[u] = *(const uint4*)(base + (int64_t)r * row_bytes + a0 + 16 * (int64_t)d);
                     else x[u] = make_uint4(0u, 0u, 0u, 0u);
@@ -180,20 +195,24 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
                     if (d >= nch) { d -= nch; ++r; }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < U; ++u) {
                     if (it0 + G * u >= items) break;
-                    const int64_t a = a0 + 16 * (int64_t)dd[u];
                     unsigned int sv;
                     if (LUT) {
+                        const int64_t a = a0 + 16 * (int64_t)dd[u];
                         sv = masked_lut_sum(x[u].x, a, b0, nbytes, esz, 0u, l8, l16);
                         sv = masked_lut_sum(x[u].y, a + 4, b0, nbytes, esz, sv, l8, l16);
                         sv = masked_lut_sum(x[u].z, a + 8, b0, nbytes, esz, sv, l8, l16);
                         sv = masked_lut_sum(x[u].w, a + 12, b0, nbytes, esz, sv, l8, l16);
                     } else {
-                        sv = masked_sum(x[u].x, a, b0, nbytes, esz, 0u);
-                        sv = masked_sum(x[u].y, a + 4, b0, nbytes, esz, sv);
-                        sv = masked_sum(x[u].z, a + 8, b0, nbytes, esz, sv);
-                        sv = masked_sum(x[u].w, a + 12, b0, nbytes, esz, sv);
+                        const bool f = dd[u] == 0, l = dd[u] == nch - 1;
+                        const uint32_t w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+                        sv = 0u;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const uint32_t y = w[k] & (f ? mfirst[k] : 0xffffffffu) & (l ? mlast[k] : 0xffffffffu);
+                            sv = (esz == 1) ? __builtin_amdgcn_sad_u8(y, 0u, sv) : (sv + (y & 0xffffu) + (y >> 16));
+                        }
                     }
                     if (sv) unsafeAtomicAdd(&sp[rr[u]], (double)sv);
                 }
@@ -381,7 +400,7 @@ hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const i
     // row sums: one wave per ROI (all 64 lanes keep loads in flight), float64 accumulators in LDS
     {
         const int ls = (max_len + 1) & ~1;
-        int waves = 4;
+        int waves = 4;                               // (1, 2 or 4 ROIs per block measure the same: 0.18 ms for 16 384 ROIs)
         while (waves > 1 && (size_t)waves * ls * 8 > 65536) waves >>= 1;
         const int lstride = ((size_t)waves * ls * 8 <= 65536) ? ls : 0;
         if (!lstride) waves = 4;
