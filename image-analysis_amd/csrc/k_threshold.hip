@@ -606,7 +606,15 @@ __global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
     // histogram took the integer path (the plane was written), the threshold has an exact integer form and sits inside
     // its own bin in integer terms: E[best] <= G_thr <= E[best+1]  (E[256] = +inf)
     const uint32_t e_lo = eg[best], e_hi = (best + 1 <= 255) ? eg[best + 1] : kGInf;
-    eg[kEdgesI_Bins] = (j.bins && eg[kEdgesI_Crit] == 0 && !crit && !(j.debug_flags & 1) && e_lo <= G_thr && G_thr <= e_hi) ? 1u : 0u;
+    // ... and iff few pixels share the threshold's class.  Every 16-pixel group holding one is read again from the image
+    // by a divergent loop in k_mask; measured, that costs more than the plane saves once ~1.5 % of the groups are
+    // touched (a photo whose threshold sits on a populated grey level: 1-99 % of the pixels on the reference's sample
+    // images; k_mask 8x slower than comparing the image).  The histogram knows the count: plane only below 1/2048 of
+    // the pixels (debug flag 4 lifts the limit, for the tests of the fix-up loop).
+    uint32_t in_class = 0;
+    for (int i = (best & ~15); i < (best & ~15) + 16; ++i) in_class += j.hist[(int64_t)img * j.hist_stride + i];
+    const bool few = (j.debug_flags & 4) || (uint64_t)in_class * 2048u <= (uint64_t)j.H * (uint64_t)j.W;
+    eg[kEdgesI_Bins] = (j.bins && few && eg[kEdgesI_Crit] == 0 && !crit && !(j.debug_flags & 1) && e_lo <= G_thr && G_thr <= e_hi) ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------------------------------------

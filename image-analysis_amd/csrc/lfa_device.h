@@ -67,7 +67,7 @@ __device__ __forceinline__ void vm_request48(const uint8_t* p, Raw48& r) {      
 }
 __device__ __forceinline__ void vm_store8(void* p, uint32_t lo, uint32_t hi) {                // 1 operation
     const uint2 v = make_uint2(lo, hi);
-    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
 }
 template <int LEFT>   // wait until at most LEFT vector memory operations of this wave are outstanding, then release r
 __device__ __forceinline__ void vm_wait48(Raw48& r) {

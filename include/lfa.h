@@ -125,8 +125,10 @@ int lfa_set_gray_variant(LfaHandle h, int variant);
 
 /* Test hook (no counterpart in the reference).  bit0: colour images take the float64 compare path even when the exact
  * integer form of the thresholds is available (that path otherwise runs only for "critical" thresholds).
- * bit1: colour images do not use the per-pixel bin plane between the histogram and the mask pass (the mask pass then
- * re-reads the image, as it does for unaligned images). */
+ * bit1: colour images do not use the per-pixel class plane between the histogram and the mask pass (the mask pass then
+ * re-reads the image, as it does for unaligned images).
+ * bit2: the class plane is used however many pixels share the threshold's class (by default only below 1/2048 of the
+ * image's pixels, because each of them sends the mask pass back to the image). */
 int lfa_set_debug_flags(LfaHandle h, int flags);
 
 /* ---- detect: detect_lateral_flow_tests(image, line_length) -- detection.py:31-94 ----------------------------------- */

@@ -103,8 +103,8 @@ def test_colour_float64_fallback_path(capi, eng, seed):
 
 def test_colour_bin_plane_paths_agree(capi, eng):
     """k_mask decides from the bin plane k_hist_rgb wrote (bin > Otsu bin: set, <: clear, ==: exact compare on the image).
-    Images with few distinct gray levels put many pixels INTO the threshold's bin; both that path and the plane-less path
-    (debug flag 2) must reproduce the oracle, and `otsu_bin` must be populated."""
+    Images with few distinct gray levels put many pixels INTO the threshold's class; the plane path with its fix-up loop
+    (debug flag 4 forces it), the plane-less path (debug flag 2) and the default choice must all reproduce the oracle."""
     rng = np.random.default_rng(2024)
     cases = []
     base = rng.integers(50, 61, size=(192, 256), dtype=np.uint8)                 # 11 levels: one value per occupied bin
@@ -121,7 +121,7 @@ def test_colour_bin_plane_paths_agree(capi, eng):
     wide[30:160, 80:96] = (250, 251, 249)
     cases.append(wide)
     for img in cases:
-        for flags in (0, 2):
+        for flags in (0, 2, 4):              # default (plane only when few pixels share the class), no plane, plane always
             eng.set_debug_flags(flags)
             try:
                 d = check_detect(capi, eng, img, 60, 10)
@@ -293,4 +293,8 @@ def test_random_small_images_against_oracle(capi, eng, seed):
             arr = np.ascontiguousarray(np.stack(ch, axis=2).astype(np.uint8))
         L = int(rng.choice([1, 2, 5, 10, 10, 10, 17]))
         mm_r, mm_c = int(rng.integers(0, max(1, H))), int(rng.integers(0, max(1, W // 2 + 1)))
-        check_detect(capi, eng, arr, mm_r, mm_c, L)
+        eng.set_debug_flags(int(rng.choice([0, 4])) if kind == 2 else 0)    # colour: default choice of the class plane, or forced
+        try:
+            check_detect(capi, eng, arr, mm_r, mm_c, L)
+        finally:
+            eng.set_debug_flags(0)
