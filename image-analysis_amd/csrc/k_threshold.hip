@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
     const uint32_t G_thr = g_threshold(T, &crit);
     eg[kEdgesI_MaskThr] = G_thr;
     eg[kEdgesI_MaskCrit] = (crit || (j.debug_flags & 1)) ? 1u : 0u;
-    // k_mask may decide from the bin plane alone (bin > best: set, bin < best: clear, bin == best: exact compare) iff the
+    // k_mask may decide from the class plane alone (class > class of best: set, <: clear, ==: exact compare) iff the
     // histogram took the integer path (the plane was written), the threshold has an exact integer form and sits inside
     // its own bin in integer terms: E[best] <= G_thr <= E[best+1]  (E[256] = +inf)
     const uint32_t e_lo = eg[best], e_hi = (best + 1 <= 255) ? eg[best + 1] : kGInf;

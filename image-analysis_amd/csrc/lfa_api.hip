@@ -200,7 +200,7 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.otsu_s = (double*)h->otsu_s.p;
     j.edges_g = (double*)h->edges.p;
     j.edges_i = (uint32_t*)h->edges_i.p;
-    // bin plane: colour images on the vector paths only (16-pixel groups in k_hist_rgb, 16-column groups in k_mask)
+    // class plane: colour images on the vector paths only (16-pixel groups in k_hist_rgb, 16-column groups in k_mask)
     j.passes_event = h->passes_event;
     j.bins = (C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2)) ? (uint8_t*)h->bins.p : nullptr;
     j.maskT = (uint64_t*)h->maskT.p;

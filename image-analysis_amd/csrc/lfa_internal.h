@@ -15,7 +15,7 @@ constexpr int kEdgesI = 264;             // integer edge record per image: 257 t
 constexpr int kEdgesI_Crit = 257;        // != 0: some histogram edge is critical -> float64 histogram path
 constexpr int kEdgesI_MaskThr = 258;     // integer form of the mask threshold
 constexpr int kEdgesI_MaskCrit = 259;    // != 0: mask threshold critical -> float64 mask path
-constexpr int kEdgesI_Bins = 260;        // != 0: the image's bin plane (Job::bins) is valid and k_mask may use it
+constexpr int kEdgesI_Bins = 260;        // != 0: the image's class plane (Job::bins) is valid and k_mask may use it
 constexpr int kAreaMin = 100;            // detection.py:81
 constexpr int kMaxCand = 1 << 20;
 

@@ -102,7 +102,7 @@ def test_colour_float64_fallback_path(capi, eng, seed):
 
 
 def test_colour_bin_plane_paths_agree(capi, eng):
-    """k_mask decides from the bin plane k_hist_rgb wrote (bin > Otsu bin: set, <: clear, ==: exact compare on the image).
+    """k_mask decides from the class plane k_hist_rgb wrote (class above the Otsu bin's: set, below: clear, equal: exact compare on the image).
     Images with few distinct gray levels put many pixels INTO the threshold's class; the plane path with its fix-up loop
     (debug flag 4 forces it), the plane-less path (debug flag 2) and the default choice must all reproduce the oracle."""
     rng = np.random.default_rng(2024)
