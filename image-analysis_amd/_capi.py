@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblfa_hip.so")
 
 LFA_U8, LFA_U16 = 0, 1
-DBG_MASK, DBG_OPENED, DBG_LABELS, DBG_TABLE, DBG_HIST = 0, 1, 2, 3, 4
+DBG_MASK, DBG_OPENED, DBG_LABELS, DBG_TABLE, DBG_HIST, DBG_PLANE = 0, 1, 2, 3, 4, 5
 GRAY_NVARIANTS = 6
 
 # numpy mirrors of the C structs (align=True reproduces the C layout)
@@ -450,6 +450,13 @@ class Engine:
         _check(lib.lfa_debug_fetch(self._h, image_index, DBG_TABLE, out.data_ptr(), max(k, 1) * 20,
                                    current_stream_ptr(self.device)))
         return out.cpu().numpy().reshape(-1, 5)[:k]
+
+    def debug_used_plane(self, image_index):
+        """True if the mask of colour image `image_index` of the last call was decided from the class plane (LFA_DBG_PLANE)."""
+        torch = _torch()
+        out = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _check(lib.lfa_debug_fetch(self._h, image_index, DBG_PLANE, out.data_ptr(), 4, current_stream_ptr(self.device)))
+        return bool(out.cpu().numpy()[0])
 
     def set_debug_flags(self, flags):
         _check(lib.lfa_set_debug_flags(self._h, int(flags)))

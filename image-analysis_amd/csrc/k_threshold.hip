@@ -26,6 +26,7 @@ namespace lfa {
 __global__ __launch_bounds__(256) void k_init_info(Job j) {
     const int img = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    if (t == 0 && img == 0 && j.plane_stats) { j.plane_stats[0] = 0u; j.plane_stats[1] = 0u; }
     if (t == 0) {
         LfaImageInfo z;
         z.xmin = 0x7fffffff; z.xmax = -1; z.v_thr = 0; z.x_thr = 0x7fffffff;
@@ -614,7 +615,9 @@ __global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
     uint32_t in_class = 0;
     for (int i = (best & ~15); i < (best & ~15) + 16; ++i) in_class += j.hist[(int64_t)img * j.hist_stride + i];
     const bool few = (j.debug_flags & 4) || (uint64_t)in_class * 2048u <= (uint64_t)j.H * (uint64_t)j.W;
-    eg[kEdgesI_Bins] = (j.bins && few && eg[kEdgesI_Crit] == 0 && !crit && !(j.debug_flags & 1) && e_lo <= G_thr && G_thr <= e_hi) ? 1u : 0u;
+    const bool could = few && eg[kEdgesI_Crit] == 0 && !crit && !(j.debug_flags & 1) && e_lo <= G_thr && G_thr <= e_hi;
+    eg[kEdgesI_Bins] = (j.bins && could) ? 1u : 0u;
+    if (j.plane_stats) { if (could) atomicAdd(&j.plane_stats[0], 1u); atomicAdd(&j.plane_stats[1], 1u); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -98,9 +98,17 @@ struct LfaContext {
     bool have_last = false;
     EventTimer* timer = nullptr;
     hipEvent_t passes_event = nullptr;     // see lfa_stream_wait_passes
+    // Class plane on/off per call (colour images).  k_otsu_rgb counts the images that could use the plane; the two counters
+    // are copied to pinned host memory behind the call's kernels and looked at -- without waiting -- when a later call is
+    // set up: while fewer than half of the images could use it, the histogram pass does not write the plane at all
+    // (photo-like inputs: 0.59 -> 0.42 ms per 256 images).  Results do not depend on the choice.
+    Buf plane_stats;
+    uint32_t* plane_host = nullptr;        // pinned, 2 words
+    hipEvent_t plane_event = nullptr;
+    bool plane_pending = false, plane_on = true;
     std::vector<Buf*> all() {
         return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_tmp, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
-                &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &lut8, &lut16, &rois};
+                &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &lut8, &lut16, &rois, &plane_stats};
     }
 };
 
@@ -202,7 +210,8 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.edges_i = (uint32_t*)h->edges_i.p;
     // class plane: colour images on the vector paths only (16-pixel groups in k_hist_rgb, 16-column groups in k_mask)
     j.passes_event = h->passes_event;
-    j.bins = (C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2)) ? (uint8_t*)h->bins.p : nullptr;
+    j.plane_stats = (C == 3) ? (uint32_t*)h->plane_stats.p : nullptr;
+    j.bins = (C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4))) ? (uint8_t*)h->bins.p : nullptr;
     j.maskT = (uint64_t*)h->maskT.p;
     j.col_cnt = (uint32_t*)h->col_cnt.p;
     j.run_tmp = (uint32_t*)h->run_tmp.p;
@@ -244,6 +253,10 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (max_strips < 1 || max_strips > 1024) return fail(LFA_ERR_ARG, "max_strips must be in [1,1024]");
     LFA_ON_DEVICE(h->device);
     if ((rc = ensure_workspace(h, n, H, W, C, dtype, L, max_strips))) return rc;
+    if (C == 3 && h->plane_pending && hipEventQuery(h->plane_event) == hipSuccess) {      // an earlier call's counters have arrived
+        h->plane_pending = false;
+        if (h->plane_host[1]) h->plane_on = 2u * h->plane_host[0] >= h->plane_host[1];
+    }
     lfa::Job j = make_job(h, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
     lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
     TimerScope ts(h);
@@ -251,6 +264,11 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     LFA_HIP(lfa::launch_mask(j, s));
     LFA_HIP(lfa::launch_label(j, s));
     LFA_HIP(lfa::launch_regions(j, o, s));
+    if (C == 3 && !h->plane_pending) {
+        LFA_HIP(hipMemcpyAsync(h->plane_host, h->plane_stats.p, 8, hipMemcpyDeviceToHost, s));
+        LFA_HIP(hipEventRecord(h->plane_event, s));
+        h->plane_pending = true;
+    }
     h->last = j; h->have_last = true;
     if (job_out) *job_out = j;
     return LFA_OK;
@@ -294,6 +312,16 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         return fail(LFA_ERR_HIP, "uploading gamma tables failed");
     }
     if ((rc = ensure_workspace(h, max_batch, max_h, max_w, max_c, LFA_U16, 10, 64))) { lfa_destroy(h); return rc; }
+    if ((rc = ensure(h->plane_stats, 8))) { lfa_destroy(h); return rc; }
+    if (hipHostMalloc((void**)&h->plane_host, 8, hipHostMallocDefault) != hipSuccess) {
+        h->plane_host = nullptr; lfa_destroy(h);
+        return fail(LFA_ERR_NOMEM, "hipHostMalloc failed");
+    }
+    h->plane_host[0] = h->plane_host[1] = 0u;
+    if (hipEventCreateWithFlags(&h->plane_event, hipEventDisableTiming) != hipSuccess) {
+        h->plane_event = nullptr; lfa_destroy(h);
+        return fail(LFA_ERR_HIP, "hipEventCreate failed");
+    }
     if (hipEventCreateWithFlags(&h->passes_event, hipEventDisableTiming) != hipSuccess) {
         h->passes_event = nullptr; lfa_destroy(h);
         return fail(LFA_ERR_HIP, "hipEventCreate failed");
@@ -307,6 +335,8 @@ int lfa_destroy(LfaHandle h) {
     DeviceGuard guard_(h->device);
     for (Buf* b : h->all()) if (b->p) (void)hipFree(b->p);
     if (h->passes_event) (void)hipEventDestroy(h->passes_event);
+    if (h->plane_event) { if (h->plane_pending) (void)hipEventSynchronize(h->plane_event); (void)hipEventDestroy(h->plane_event); }
+    if (h->plane_host) (void)hipHostFree(h->plane_host);
     delete h->timer;
     delete h;
     return LFA_OK;

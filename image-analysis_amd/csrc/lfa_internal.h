@@ -43,6 +43,8 @@ struct Job {
     double* edges_g;         // [n][257]  gray-space bin edges (colour path)
     uint32_t* edges_i;       // [n][264]  the same as integer thresholds on G = 2125*b0 + 7154*b1 + 721*b2 (k_threshold.hip)
     hipEvent_t passes_event; // recorded on the launch stream right after the histogram pass (lfa_stream_wait_passes); may be null
+    uint32_t* plane_stats;   // [2]  colour images of this call whose mask could be decided from the class plane / colour images seen
+                             //      (k_otsu_rgb counts; the host reads them later to decide whether the next call writes the plane)
     uint8_t* bins;           // [n][H*W/2]  colour path: class plane, (histogram bin >> 4) of every pixel in 4 bits, written by
                              //             k_hist_rgb and read by k_mask instead of the image (0.5 byte per pixel instead of 3);
                              //             null = not used

@@ -130,6 +130,61 @@ def test_colour_bin_plane_paths_agree(capi, eng):
         assert d["mask"].any() and not d["mask"].all()
 
 
+def _valley_image(rng, H=192, W=256):
+    """dark background, bright strips and five stray pixels in between: the Otsu bin is the strays' bin, and only they
+    share its class"""
+    g = rng.integers(30, 41, size=(H, W)).astype(np.uint8)
+    for c0 in (40, 120, 200):
+        g[20:170, c0:c0 + 12] = rng.integers(190, 210, size=(150, 12))
+    for k in range(5):
+        g[5 + k, 3 + 17 * k] = 60
+    return np.ascontiguousarray(np.stack([g, g, g], axis=2))
+
+
+def _photo_image(rng, H=192, W=256):
+    """smooth ramp under the strips: every grey level is populated, thousands of pixels share the threshold's class"""
+    ramp = np.linspace(20, 235, W)[None, :] + rng.normal(0, 3, size=(H, W))
+    g = np.clip(ramp, 0, 255).astype(np.uint8)
+    g[20:170, 60:72] = 250
+    return np.ascontiguousarray(np.stack([g, g, g], axis=2))
+
+
+def _few_share_the_class(img):
+    """the rule of k_otsu_rgb, from the oracle's histogram: pixels in the 16 bins of the Otsu bin's class <= H*W / 2048"""
+    v = O.adjust_gamma(O.rgb2gray(img), 0.4)
+    counts, centers = O.histogram_image_range(v)
+    best = O.otsu_from_hist(counts, centers)[1]
+    return int(counts[(best & ~15):(best & ~15) + 16].sum()) * 2048 <= img.shape[0] * img.shape[1]
+
+
+def test_class_plane_is_chosen_per_image_and_per_call(capi):
+    """k_otsu_rgb lets an image use the class plane only when few pixels share the threshold's class; a handle stops
+    writing the plane while most images of its last completed call could not use it, and starts again when they can.
+    Every intermediate is checked against the oracle whichever way the choice goes."""
+    rng = np.random.default_rng(99)
+    eng = capi.Engine(device=0, max_h=192, max_w=256, max_batch=4)
+    try:
+        valley = np.stack([_valley_image(rng) for _ in range(4)])
+        photo = np.stack([_photo_image(rng) for _ in range(4)])
+        assert all(_few_share_the_class(v) for v in valley) and not any(_few_share_the_class(p) for p in photo)
+        mixed = np.stack([valley[0], photo[0], valley[1], valley[2]])
+
+        def run(batch):
+            res = eng.detect(batch, 60, 10)
+            for i in range(len(batch)):
+                check_detect(capi, eng, batch[i], 60, 10, batch_index=i, res=res)
+            return [eng.debug_used_plane(i) for i in range(len(batch))]
+        assert run(mixed) == [True, False, True, True]              # per image
+        assert run(photo) == [False] * 4                            # 3 of 4 could before: plane still written, nobody uses it
+        assert run(valley) == [False] * 4                           # last call: 0 of 4 could -> this call wrote no plane
+        assert run(valley) == [True] * 4                            # last call: 4 of 4 could have -> plane back on
+        eng.set_debug_flags(4)
+        assert run(photo) == [True] * 4                             # forced: the fix-up loop settles the pixels of the class
+        eng.set_debug_flags(0)
+    finally:
+        eng.close()
+
+
 def test_colour_extreme_values(capi, eng):
     """black and saturated pixels, all 256 levels per channel, strongly different channels"""
     rng = np.random.default_rng(77)
