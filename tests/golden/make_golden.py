@@ -13,6 +13,10 @@ What it produces (all of it data: inputs + expected outputs, no reference source
 * ref_region_lists.npz                  inputs + outputs of detection.py:118-153 (check_duplicate, remove_outliers).
 * image1_decoded.npz                    images/image1.jpg decoded with PIL (cv2 is absent here; the decoded
                                         array is stored because decoders may differ by an LSB).
+* real_samples.npz                      seven more of the reference's sample inputs (images/), decoded with PIL: three
+                                        512x512 grey JPEGs, the one colour photo (BGR), 768x1024 crops of two large
+                                        grey JPEGs and of the 16-bit PNG.  Inputs only; `--only-samples` writes just
+                                        this file.
 
 The reference module cannot be imported as a whole (cv2 / tifffile / skimage / tkinter / xlsxwriter are not
 installed and it opens a Tk window at import, detection.py:787-789); the numpy-only line ranges above are
@@ -180,8 +184,29 @@ def main():
     # ---- decoded sample image ------------------------------------------------------------------
     im = np.array(Image.open(os.path.join(REF, "images", "image1.jpg")))
     np.savez_compressed(os.path.join(HERE, "image1_decoded.npz"), gray=im)
+    write_real_samples()
     print("golden fixtures written:", sorted(os.listdir(HERE)))
 
 
+def write_real_samples():
+    """More of the reference's sample inputs (images/), decoded with PIL and stored as arrays: the small ones whole, a
+    768x1024 crop of three large ones.  They are INPUTS only -- photo-like data on which the Otsu threshold sits on a
+    populated grey level (the case the synthetic benchmark images do not have); expected values come from the oracle
+    at test time."""
+    out = {}
+    for name in ("image2.jpeg", "image4.jpg", "image7.jpg"):                    # 512x512 grey JPEGs
+        out[name.split(".")[0]] = np.array(Image.open(os.path.join(REF, "images", name)))
+    rgb = np.array(Image.open(os.path.join(REF, "images", "test_strip_buggy.jpeg")).convert("RGB"))
+    out["test_strip_buggy_bgr"] = np.ascontiguousarray(rgb[:, :, ::-1])        # cv2.imread order
+    for name, key in (("WickImage.jpg", "wick_crop"), ("image5.jpg", "image5_crop")):
+        a = np.array(Image.open(os.path.join(REF, "images", name)))
+        out[key] = np.ascontiguousarray(a[640:1408, 512:1536])
+    a16 = np.array(Image.open(os.path.join(REF, "images", "Austin's Image.png"))).astype(np.uint16)
+    out["austin_u16_crop"] = np.ascontiguousarray(a16[640:1408, 512:1536])
+    np.savez_compressed(os.path.join(HERE, "real_samples.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--only-samples" in sys.argv:
+        sys.exit(write_real_samples())
     sys.exit(main())

@@ -78,6 +78,28 @@ def test_image1_gray_and_bgr(capi, eng, golden_dir):
     check_detect(capi, eng, bgr, mm_r, mm_c)
 
 
+@pytest.mark.parametrize("key", ["image2", "image4", "image7", "test_strip_buggy_bgr", "wick_crop", "image5_crop", "austin_u16_crop"])
+def test_reference_sample_images(capi, golden_dir, key):
+    """The reference's own sample inputs (tests/golden/real_samples.npz, decoded in the build container): photo-like data,
+    thresholds on populated grey levels, hundreds of labels.  Grey JPEGs go through the 2-D path and -- as three equal
+    channels, which is what cv2.imread hands the reference -- through the colour path, with the class plane left to the
+    default choice and forced."""
+    img = np.load(os.path.join(golden_dir, "real_samples.npz"))[key]
+    H, W = img.shape[:2]
+    eng = capi.Engine(device=0, max_h=H, max_w=W, max_batch=1)
+    try:
+        mm_r, mm_c = gui_params(img)
+        check_detect(capi, eng, img, mm_r, mm_c)
+        if img.dtype == np.uint8:
+            bgr = img if img.ndim == 3 else np.ascontiguousarray(np.repeat(img[:, :, None], 3, axis=2))
+            for flags in (0, 4):
+                eng.set_debug_flags(flags)
+                check_detect(capi, eng, bgr, mm_r, mm_c)
+            eng.set_debug_flags(0)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_synthetic_rgb(capi, eng, seed):
     from image_analysis_amd.synth import synth_rgb

@@ -136,6 +136,21 @@ def _check_analyze(eng, imgs, mm_r, mm_c):
     return total, info
 
 
+@pytest.mark.parametrize("key", ["image2", "image7", "test_strip_buggy_bgr", "wick_crop", "austin_u16_crop"])
+def test_analyze_reference_sample_images(golden_dir, key):
+    """detect + profile + peaks on the reference's sample inputs (tests/golden/real_samples.npz) against the oracle."""
+    import image_analysis_amd._capi as capi
+    img = np.load(os.path.join(golden_dir, "real_samples.npz"))[key]
+    if img.dtype == np.uint8 and img.ndim == 2:
+        img = np.ascontiguousarray(np.repeat(img[:, :, None], 3, axis=2))       # cv2.imread of a grey JPEG
+    eng = capi.Engine(device=0, max_h=img.shape[0], max_w=img.shape[1], max_batch=1)
+    try:
+        mm_c = int(img.shape[1] / 40)
+        _check_analyze(eng, img[None], mm_c * 20, mm_c)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("dtype,c", [(np.uint8, 0), (np.uint8, 3), (np.uint16, 0)])
 def test_analyze_many_candidates_overflow_the_row_sum_pool(dtype, c):
     """More strips than the window row-sum pool (16*H entries) holds: later strips take the pixel path; boxes are clipped
