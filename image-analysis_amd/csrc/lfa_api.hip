@@ -333,9 +333,10 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
 int lfa_destroy(LfaHandle h) {
     if (!h) return LFA_OK;
     DeviceGuard guard_(h->device);
+    if (h->plane_event && h->plane_pending) (void)hipEventSynchronize(h->plane_event);   // the counters' copy reads plane_stats and writes plane_host
     for (Buf* b : h->all()) if (b->p) (void)hipFree(b->p);
     if (h->passes_event) (void)hipEventDestroy(h->passes_event);
-    if (h->plane_event) { if (h->plane_pending) (void)hipEventSynchronize(h->plane_event); (void)hipEventDestroy(h->plane_event); }
+    if (h->plane_event) (void)hipEventDestroy(h->plane_event);
     if (h->plane_host) (void)hipHostFree(h->plane_host);
     delete h->timer;
     delete h;
