@@ -93,6 +93,46 @@ def bench_big(B=128, CH=64, pool=4):
         e.close()
 
 
+def bench_photo(B=1024, CH=256, pool=8):
+    """configs[1]'s shape on photo-like content: the decoded reference sample tests/golden/image1_decoded.npz (512x512 grey,
+    what cv2.imread turns into three equal channels), tiled to 1536x2048x3 with a different shift per image.  Many pixels
+    share the Otsu threshold's class here, so the handles stop writing the class plane and the mask pass compares the
+    image."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "image1_decoded.npz"))["gray"]
+    H, W = 1536, 2048
+    tile = np.tile(g, (3, 4))
+    pool_np = np.stack([np.repeat(np.roll(tile, (37 * i, 91 * i), (0, 1))[:, :, None], 3, axis=2) for i in range(pool)])
+    p = torch.from_numpy(pool_np.reshape(pool, -1)).to(dev)
+    batch = p[torch.arange(B, device=dev) % pool].contiguous()
+    ms, stride = 64, int(H * .6) + 1
+    engs = [capi.Engine(device=0, max_h=H, max_w=W, max_c=3, max_batch=CH) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    strips = capi.dev_bytes(B * ms * 24, dev); counts = torch.zeros(B, dtype=torch.int32, device=dev)
+    info = capi.dev_bytes(B * 104, dev); rois = capi.dev_bytes(B * ms * 20, dev)
+    prof = torch.empty(B * ms * stride, dtype=torch.float64, device=dev); peaks = capi.dev_bytes(B * ms * 40, dev)
+    ib = H * W * 3
+    torch.cuda.synchronize()
+
+    def step(ns=2):
+        for ci, b0 in enumerate(range(0, B, CH)):
+            capi._check(capi.lib.lfa_analyze_batch(engs[ci % ns]._h, batch.data_ptr() + b0 * ib, capi.LFA_U8, CH, H, W, 3, 1020, 51, 10,
+                        strips.data_ptr() + b0 * ms * 24, ms, counts.data_ptr() + b0 * 4, info.data_ptr() + b0 * 104,
+                        rois.data_ptr() + b0 * ms * 20, prof.data_ptr() + b0 * ms * stride * 8, stride,
+                        peaks.data_ptr() + b0 * ms * 40, C.c_void_p(streams[ci % ns].cuda_stream)))
+    step(); torch.cuda.synchronize(); step(); torch.cuda.synchronize()      # the handles settle their class-plane choice
+    dt = timed(step)
+    engs[0].timing("*"); step(1); torch.cuda.synchronize(); kt = engs[0].timing_read(); engs[0].timing(None)
+    inf = capi.from_device(info, capi.INFO_DT, B)
+    assert (inf["status"] == 0).all()
+    print(json.dumps({"config": "photo-like colour images 1536x2048x3 (reference sample image1, tiled)", "images": B,
+                      "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(B / dt, 1), "strips_per_s": round(int(counts.sum().item()) / dt, 1),
+                      "labels_mean": float(inf["n_labels"].mean()), "e2e_frac_hbm": round(B / dt * ib / 8e12, 4),
+                      "kernel_ms_one_stream": {k: round(v[0], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])[:8]}}))
+    for e in engs:
+        e.close()
+
+
 def bench_rois(B=64, per=256):
     H, W = 1536, 2048
     pool_np = np.stack([synth.synth_rgb(H, W, 8, 1234 + i) for i in range(8)])
@@ -178,6 +218,7 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["u16", "rois", "gauss"]
     if "u16" in what: bench_u16()
     if "big" in what: bench_big()
+    if "photo" in what: bench_photo()
     if "rois" in what: bench_rois()
     if "gauss" in what: bench_gauss()
     if "peaks" in what: bench_peaks()

@@ -125,49 +125,73 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
     const int nc = inf->n_candidates;
     const int lane = threadIdx.x;
     const int cap = min(j.max_strips, kMaxStripsLds);
-    __shared__ Acc acc[kMaxStripsLds];
-    __shared__ Acc kept[kMaxStripsLds];
+    // accepted / kept lists: dynamic LDS sized to the call's max_strips.  This wave runs beside the other chunk stream's
+    // image passes, which leave little LDS free on a CU: with the lists at their 1024-entry maximum (56 KiB) the block
+    // waited for several of those blocks to retire (measured: 1.5 % of the whole pipeline).
+    extern __shared__ __align__(16) unsigned char fin_smem[];
+    Acc* acc = (Acc*)fin_smem;
+    Acc* kept = acc + cap;
     int na = 0;
     int status = 0;
     const int64_t cbase = (int64_t)img * j.cand_cap;
     const double bg = (double)inf->label00;                   // detection.py:67: the label id at (0,0)
-    for (int ci = 0; ci < nc; ++ci) {                         // uniform: every lane walks the same candidates
-        const int lab = j.cand[cbase + ci];
-        const int root = j.root_of_label[rbase + lab - 1];
-        const Box bx = cand_box(j, rbase, root);
-        const int minr = bx.minr, minc = bx.minc, maxr = bx.maxr, maxc = bx.maxc;
-        if (inf->label00 != 0) {   // np.mean of the clipped box (detection.py:76-81); always > 0 when the corner is background
-            // exact integer sums, then the reference's divisions
-            const double cnt = (double)((long long)(bx.cr - minr) * (long long)(bx.cc - minc));
-            const unsigned long long* cs = j.cand_sum + (cbase + ci) * 3;
-            double m;
-            if (j.C == 3) {
-                const double m0 = (double)cs[0] / cnt, m1 = (double)cs[1] / cnt, m2 = (double)cs[2] / cnt;
-                m = ((m0 + m1) + m2) / 3.0;
+    // The accept loop is sequential (a candidate is tested against everything accepted before it), but what it reads is
+    // not: the lanes fetch label, root, box and the region test of kStage candidates at once into LDS -- three dependent
+    // global loads per candidate that the loop would otherwise wait for one candidate at a time (images with hundreds
+    // of candidates: 120 us -> a few) -- and the loop then runs on LDS.
+    constexpr int kStage = 256;
+    __shared__ int s_box[kStage][4];
+    __shared__ int s_root[kStage], s_lab[kStage];
+    __shared__ unsigned char s_ok[kStage];
+    for (int c0 = 0; c0 < nc && !status; c0 += kStage) {
+        const int m = min(kStage, nc - c0);
+        for (int k = lane; k < m; k += 64) {
+            const int ci = c0 + k;
+            const int lab = j.cand[cbase + ci];
+            const int root = j.root_of_label[rbase + lab - 1];
+            const Box bx = cand_box(j, rbase, root);
+            bool ok = true;
+            if (inf->label00 != 0) {   // np.mean of the clipped box (detection.py:76-81); always > 0 when the corner is background
+                // exact integer sums, then the reference's divisions
+                const double cnt = (double)((long long)(bx.cr - bx.minr) * (long long)(bx.cc - bx.minc));
+                const unsigned long long* cs = j.cand_sum + (cbase + ci) * 3;
+                double mean;
+                if (j.C == 3) {
+                    const double m0 = (double)cs[0] / cnt, m1 = (double)cs[1] / cnt, m2 = (double)cs[2] / cnt;
+                    mean = ((m0 + m1) + m2) / 3.0;
+                } else {
+                    mean = (double)cs[0] / cnt;
+                }
+                ok = mean > bg;
+            }
+            s_box[k][0] = bx.minr; s_box[k][1] = bx.maxr; s_box[k][2] = bx.minc; s_box[k][3] = bx.maxc;
+            s_root[k] = root; s_lab[k] = lab; s_ok[k] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        for (int k = 0; k < m; ++k) {                          // uniform: every lane walks the same candidates
+            if (!s_ok[k]) continue;
+            const int minr = s_box[k][0], maxr = s_box[k][1], minc = s_box[k][2], maxc = s_box[k][3];
+            bool hit = false;
+            for (int q = lane; q < na; q += 64) {
+                const Acc a = acc[q];
+                hit |= (minr <= a.maxr && maxr >= a.minr && minc <= a.maxc && maxc >= a.minc);
+            }
+            if (__any(hit)) continue;
+            if (na < cap) {
+                if (lane == 0) {
+                    Acc a; a.minr = minr; a.maxr = maxr; a.minc = minc; a.maxc = maxc;
+                    a.area = j.area[rbase + s_root[k]]; a.label = s_lab[k]; a.rs_off = j.cand_rs_off[cbase + c0 + k];
+                    acc[na] = a;
+                }
+                __syncthreads();
+                ++na;
             } else {
-                m = (double)cs[0] / cnt;
+                status |= 1;                                  // out of room: later duplicate tests would be incomplete
+                ++na;
+                break;
             }
-            if (!(m > bg)) continue;
         }
-        bool hit = false;
-        for (int k = lane; k < na; k += 64) {
-            const Acc a = acc[k];
-            hit |= (minr <= a.maxr && maxr >= a.minr && minc <= a.maxc && maxc >= a.minc);
-        }
-        if (__any(hit)) continue;
-        if (na < cap) {
-            if (lane == 0) {
-                Acc a; a.minr = minr; a.maxr = maxr; a.minc = minc; a.maxc = maxc;
-                a.area = j.area[rbase + root]; a.label = lab; a.rs_off = j.cand_rs_off[cbase + ci];
-                acc[na] = a;
-            }
-            __syncthreads();
-            ++na;
-        } else {
-            status |= 1;                                      // out of room: later duplicate tests would be incomplete
-            ++na;
-            break;
-        }
+        __syncthreads();
     }
     __syncthreads();
     const int na_c = min(na, cap);
@@ -221,7 +245,8 @@ hipError_t launch_regions(const Job& j, const OutPtrs& o, hipStream_t s) {
     if (gx < 16) gx = 16;
     if (gx > 256) gx = 256;
     LFA_LAUNCH("k_box_sums", k_box_sums, dim3(gx, j.n), dim3(256), 0, s, j);
-    LFA_LAUNCH("k_finalize", k_finalize, dim3(j.n), dim3(64), 0, s, j, o);
+    const size_t fin_lds = (size_t)2 * (j.max_strips < kMaxStripsLds ? j.max_strips : kMaxStripsLds) * sizeof(Acc);
+    LFA_LAUNCH("k_finalize", k_finalize, dim3(j.n), dim3(64), fin_lds, s, j, o);
     return hipGetLastError();
 }
 

@@ -136,6 +136,21 @@ def _check_analyze(eng, imgs, mm_r, mm_c):
     return total, info
 
 
+def test_analyze_with_the_largest_strip_list():
+    """max_strips = 1024 is the API's upper limit: k_finalize's accepted / kept lists (dynamic LDS) are then at their largest."""
+    import image_analysis_amd._capi as capi
+    from image_analysis_amd.synth import synth_rgb
+    imgs = np.stack([synth_rgb(384, 512, 8, 300 + i) for i in range(2)])
+    eng = capi.Engine(device=0, max_h=384, max_w=512, max_batch=2)
+    try:
+        res, info = eng.analyze(imgs, 240, 12, max_strips=1024)
+        for i, (strips, profiles, peaks) in enumerate(res):
+            d = O.detect_debug(imgs[i], 240, 12)
+            assert [[int(s["minr"]), int(s["maxr"]), int(s["minc"]), int(s["maxc"])] for s in strips] == d["strips"] and len(strips) >= 4
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("key", ["image2", "image7", "test_strip_buggy_bgr", "wick_crop", "austin_u16_crop"])
 def test_analyze_reference_sample_images(golden_dir, key):
     """detect + profile + peaks on the reference's sample inputs (tests/golden/real_samples.npz) against the oracle."""
