@@ -30,7 +30,6 @@ parity is pinned on scipy.ndimage/numpy semantics only.
 """
 from __future__ import annotations
 
-import math
 import warnings
 
 import numpy as np

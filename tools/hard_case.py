@@ -7,7 +7,7 @@ import importlib, json, sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 capi = importlib.import_module("image_analysis_amd._capi")
-import ctypes as C
+
 
 dev = torch.device("cuda", 0)
 g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "image1_decoded.npz"))["gray"]

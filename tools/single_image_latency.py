@@ -2,7 +2,7 @@
 """Latency of the drop-in calls on ONE host image (the GUI's case: one file per click, detection.py:462, :541-543):
 detect_lateral_flow_tests + image_analysis of every strip, host array in, host results out."""
 import importlib, json, os, sys, time
-import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 det = importlib.import_module("image_analysis_amd.detection")
 synth = importlib.import_module("image_analysis_amd.synth")
