@@ -587,14 +587,38 @@ __global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
         var[t] = (double)ww * (d * d);
     }
     __syncthreads();
-    if (t != 0) return;
-    int best = 0;
-    double bv = var[0];
-    if (!lfa_isnan(bv))
-        for (int i = 1; i < 255; ++i) {
-            const double v = var[i];
-            if (!(v <= bv)) { bv = v; best = i; if (lfa_isnan(v)) break; }
+    // np.argmax(variance12): the first NaN if there is one, else the first index of the maximum -- as a reduction (the
+    // scan by one lane, 255 dependent LDS reads, was 18 us of this kernel's 45)
+    __shared__ double s_av[4];
+    __shared__ int s_ai[4], s_an[4];
+    {
+        double v = (t < 255) ? var[t] : -1.0;                      // variances are >= 0 or NaN
+        const bool isn = lfa_isnan(v);
+        const unsigned long long nb = __ballot(isn);
+        if (isn) v = -1.0;
+        int idx = t;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double v2 = __shfl_xor(v, o);
+            const int i2 = __shfl_xor(idx, o);
+            if (v2 > v || (v2 == v && i2 < idx)) { v = v2; idx = i2; }
         }
+        if ((t & 63) == 0) {
+            s_av[t >> 6] = v; s_ai[t >> 6] = idx;
+            s_an[t >> 6] = nb ? ((t & ~63) + __ffsll((unsigned long long)nb) - 1) : 0x7fffffff;
+        }
+    }
+    __syncthreads();
+    if (t != 0) return;
+    int best = s_ai[0], first_nan = s_an[0];
+    {
+        double bv = s_av[0];
+        for (int k = 1; k < 4; ++k) {
+            if (s_av[k] > bv) { bv = s_av[k]; best = s_ai[k]; }    // strict: the earlier wave keeps a tie
+            first_nan = min(first_nan, s_an[k]);
+        }
+        if (first_nan != 0x7fffffff) best = first_nan;
+    }
     const double centre = ctr[best];
     inf->otsu_bin = best; inf->v_thr_f = centre;
     // mask = pow(gray, 0.4) > centre  <=>  gray >= T  with T the first double whose power exceeds the centre
