@@ -235,8 +235,10 @@ def main():
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": f"timed region runs {NS} chunk streams, so this launch time includes the other stream's kernels "
-                            "running beside it; `isolated` is the same kernel in one extra untimed step on a single stream"}
+                    "note": f"timed region runs {NS} chunk streams: a launch shares the CUs with the other stream's passes and "
+                            "tail kernels, so `frac` says how much else ran beside the kernel, not how well it uses the memory "
+                            "system; `isolated` is the same kernel in one extra untimed step on a single stream "
+                            "(--stagger 1 keeps the pass alone in the timed region: frac 0.56, throughput -5 %)"}
             if dominant in step_times and step_times[dominant][1] > 0:
                 iso_ms = step_times[dominant][0] / step_times[dominant][1]
                 roof["isolated"] = {"avg_launch_ms": round(iso_ms, 4), "achieved": round(alg_bytes / (iso_ms * 1e-3) / 1e9, 1),
