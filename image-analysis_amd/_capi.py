@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblfa_hip.so")
 
 LFA_U8, LFA_U16 = 0, 1
-DBG_MASK, DBG_OPENED, DBG_LABELS, DBG_TABLE, DBG_HIST, DBG_PLANE = 0, 1, 2, 3, 4, 5
+DBG_MASK, DBG_OPENED, DBG_LABELS, DBG_TABLE, DBG_HIST, DBG_PLANE, DBG_ONEPASS = 0, 1, 2, 3, 4, 5, 6
 GRAY_NVARIANTS = 6
 
 # numpy mirrors of the C structs (align=True reproduces the C layout)
@@ -456,6 +456,13 @@ class Engine:
         torch = _torch()
         out = torch.zeros(1, dtype=torch.int32, device=self.device)
         _check(lib.lfa_debug_fetch(self._h, image_index, DBG_PLANE, out.data_ptr(), 4, current_stream_ptr(self.device)))
+        return bool(out.cpu().numpy()[0])
+
+    def debug_one_pass(self):
+        """True if the last call took the one-pass uint16 histogram (LFA_DBG_ONEPASS)."""
+        torch = _torch()
+        out = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _check(lib.lfa_debug_fetch(self._h, 0, DBG_ONEPASS, out.data_ptr(), 4, current_stream_ptr(self.device)))
         return bool(out.cpu().numpy()[0])
 
     def set_debug_flags(self, flags):

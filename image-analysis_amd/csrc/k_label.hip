@@ -319,6 +319,13 @@ __global__ void k_dbg_table(Job j, int img, int32_t* out, int kmax) {
     }
 }
 
+__global__ void k_dbg_hist_abs(Job j, int img, uint32_t* out, int nb) {
+    const uint32_t* gh = j.hist + (int64_t)img * j.hist_stride;
+    const int xmin = j.info[img].xmin;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += gridDim.x * blockDim.x)
+        out[k] = (xmin >= 0 && xmin + k < j.hist_stride) ? gh[xmin + k] : 0u;
+}
+
 hipError_t launch_debug(const Job& j, int image, int what, void* out, int64_t out_bytes, hipStream_t s) {
     const int64_t npix = (int64_t)j.H * j.W;
     hipError_t e;
@@ -344,10 +351,20 @@ hipError_t launch_debug(const Job& j, int image, int what, void* out, int64_t ou
             break;
         case LFA_DBG_HIST: {
             const int64_t nb = out_bytes / 4 < j.hist_stride ? out_bytes / 4 : j.hist_stride;
+            if (j.hist_abs) {                                        // one-pass uint16 histogram: bins are absolute, hand out [xmin, ...)
+                hipLaunchKernelGGL(k_dbg_hist_abs, dim3(64), dim3(256), 0, s, j, image, (uint32_t*)out, (int)nb);
+                break;
+            }
             e = hipMemcpyAsync(out, j.hist + (int64_t)image * j.hist_stride, nb * 4, hipMemcpyDeviceToDevice, s);
             if (e != hipSuccess) return e;
             break;
         }
+        case LFA_DBG_ONEPASS:
+            if (out_bytes < 4) return hipErrorInvalidValue;
+            e = hipMemsetAsync(out, j.hist_abs ? 1 : 0, 1, s);
+            if (e == hipSuccess) e = hipMemsetAsync((char*)out + 1, 0, 3, s);
+            if (e != hipSuccess) return e;
+            break;
         case LFA_DBG_PLANE:
             if (out_bytes < 4) return hipErrorInvalidValue;
             if (j.C == 3 && j.bins) e = hipMemcpyAsync(out, j.edges_i + (int64_t)image * kEdgesI + kEdgesI_Bins, 4, hipMemcpyDeviceToDevice, s);

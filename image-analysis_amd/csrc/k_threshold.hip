@@ -26,7 +26,7 @@ namespace lfa {
 __global__ __launch_bounds__(256) void k_init_info(Job j) {
     const int img = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    if (t == 0 && img == 0 && j.plane_stats) { j.plane_stats[0] = 0u; j.plane_stats[1] = 0u; }
+    if (t == 0 && img == 0 && j.plane_stats) { j.plane_stats[0] = 0u; j.plane_stats[1] = 0u; j.plane_stats[2] = 0u; j.plane_stats[3] = 0u; }
     if (t == 0) {
         LfaImageInfo z;
         z.xmin = 0x7fffffff; z.xmax = -1; z.v_thr = 0; z.x_thr = 0x7fffffff;
@@ -243,12 +243,12 @@ __global__ __launch_bounds__(256) void k_hist_u8(Job j) {
     if (tot) atomicAdd(&j.hist[(int64_t)img * j.hist_stride + threadIdx.x], tot);
 }
 
-constexpr int kLdsBinsU16 = 16384;
 
 __global__ __launch_bounds__(1024) void k_hist_u16(Job j) {
     __shared__ uint32_t sh[kLdsBinsU16];
     const int img = blockIdx.y;
-    const int xmin = j.info[img].xmin, xmax = j.info[img].xmax;
+    // one-pass mode (Job::hist_abs): bins are the pixel values themselves, no range known or needed beforehand
+    const int xmin = j.hist_abs ? 0 : j.info[img].xmin, xmax = j.hist_abs ? 65535 : j.info[img].xmax;
     if (xmax <= xmin) return;                       // constant image: no histogram needed (all-equal shortcut)
     const int nb = xmax - xmin + 1;
     const int nlds = nb < kLdsBinsU16 ? nb : kLdsBinsU16;
@@ -260,6 +260,7 @@ __global__ __launch_bounds__(1024) void k_hist_u16(Job j) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     int64_t done = 0;
+    int olo = 0x7fffffff, ohi = -1;                              // occupied range seen by this thread (bins; one-pass form)
     if (j.aligned16) {
         const int64_t ng = npix >> 3;
         const uint4* v = (const uint4*)base;
@@ -269,20 +270,24 @@ __global__ __launch_bounds__(1024) void k_hist_u16(Job j) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int a = (int)(w[k] & 0xffffu) - xmin, b = (int)(w[k] >> 16) - xmin;
-                if (a < kLdsBinsU16) atomicAdd(&sh[a], 1u); else atomicAdd(&gh[a], 1u);
-                if (b < kLdsBinsU16) atomicAdd(&sh[b], 1u); else atomicAdd(&gh[b], 1u);
+                if (a < kLdsBinsU16) atomicAdd(&sh[a], 1u); else { atomicAdd(&gh[a], 1u); ohi = max(ohi, a); olo = min(olo, a); }
+                if (b < kLdsBinsU16) atomicAdd(&sh[b], 1u); else { atomicAdd(&gh[b], 1u); ohi = max(ohi, b); olo = min(olo, b); }
             }
         }
         done = ng << 3;
     }
     for (int64_t p = done + tid; p < npix; p += nth) {
         const int a = (int)base[p] - xmin;
-        if (a < kLdsBinsU16) atomicAdd(&sh[a], 1u); else atomicAdd(&gh[a], 1u);
+        if (a < kLdsBinsU16) atomicAdd(&sh[a], 1u); else { atomicAdd(&gh[a], 1u); ohi = max(ohi, a); olo = min(olo, a); }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < nlds; k += blockDim.x) {
         const uint32_t c = sh[k];
-        if (c) atomicAdd(&gh[k], c);
+        if (c) { atomicAdd(&gh[k], c); ohi = max(ohi, k); olo = min(olo, k); }
+    }
+    if (j.hist_abs) {                                            // one-pass form: the occupied range falls out of the flush
+        olo = wave_min_i32(olo); ohi = wave_max_i32(ohi);
+        if ((threadIdx.x & 63) == 0 && ohi >= 0) { atomicMin(&j.info[img].xmin, olo); atomicMax(&j.info[img].xmax, ohi); }
     }
 }
 
@@ -445,6 +450,7 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
     __shared__ double s_bv[256];
     __shared__ int s_bi[256];
     int xmin, xmax;
+    const bool abs_hist = j.dtype == LFA_U8 || j.hist_abs;      // bins are pixel values
     if (j.dtype == LFA_U8) {
         // histogram covers 0..255; find occupied range
         if (t == 0) { s_lo = 0x7fffffff; s_hi = -1; }
@@ -454,9 +460,10 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
         xmin = s_lo; xmax = s_hi;
         if (t == 0) { inf->xmin = xmin; inf->xmax = xmax; }
     } else {
-        xmin = inf->xmin; xmax = inf->xmax;
+        xmin = inf->xmin; xmax = inf->xmax;                     // from k_minmax_u16, or from k_hist_u16 in its one-pass form
     }
-    const int base_bin = (j.dtype == LFA_U8) ? xmin : 0;        // uint16 histogram is stored relative to xmin
+    if (t == 0 && j.dtype == LFA_U16 && j.plane_stats) { atomicMax(&j.plane_stats[2], (uint32_t)max(xmax, 0)); atomicAdd(&j.plane_stats[3], 1u); }
+    const int base_bin = abs_hist ? xmin : 0;                   // two-pass uint16 histogram is stored relative to xmin
     const int nb = xmax - xmin + 1;
     auto lut = [&](int x) -> int { return (j.dtype == LFA_U8) ? (int)j.lut8[x] : (int)j.lut16[x]; };
     if (nb <= 1) {
@@ -700,9 +707,15 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
         if (j.passes_event) (void)hipEventRecord(j.passes_event, s);
         LFA_LAUNCH("k_otsu_int", k_otsu_int, dim3(j.n), dim3(256), 0, s, j);
     } else {
-        const dim3 grid(blocks_per_image(j, 256 * 64), j.n);
-        LFA_LAUNCH("k_minmax_u16", k_minmax_u16, grid, dim3(256), 0, s, j);
-        LFA_LAUNCH("k_zero_hist_u16", k_zero_hist_u16, dim3(16, j.n), dim3(256), 0, s, j);
+        if (j.hist_abs) {
+            // one pass: bins = pixel values, the range falls out of the histogram (k_otsu_int)
+            const hipError_t e = hipMemsetAsync(j.hist, 0, (size_t)j.n * kHistBinsU16 * sizeof(uint32_t), s);
+            if (e != hipSuccess) return e;
+        } else {
+            const dim3 grid(blocks_per_image(j, 256 * 64), j.n);
+            LFA_LAUNCH("k_minmax_u16", k_minmax_u16, grid, dim3(256), 0, s, j);
+            LFA_LAUNCH("k_zero_hist_u16", k_zero_hist_u16, dim3(16, j.n), dim3(256), 0, s, j);
+        }
         const dim3 gridh(blocks_per_image(j, 1024 * 64), j.n);
         LFA_LAUNCH("k_hist_u16", k_hist_u16, gridh, dim3(1024), 0, s, j);
         if (j.passes_event) (void)hipEventRecord(j.passes_event, s);

@@ -106,6 +106,10 @@ struct LfaContext {
     uint32_t* plane_host = nullptr;        // pinned, 2 words
     hipEvent_t plane_event = nullptr;
     bool plane_pending = false, plane_on = true;
+    // uint16 images: the histogram pass needs no min/max pass before it when the bins are the pixel values themselves (one
+    // pass less over the image); worth it while the values stay below the LDS table of k_hist_u16 (camera data of 12-14
+    // bits).  Chosen from the largest value of the last completed uint16 call, which travels with the counters above.
+    bool u16_one_pass = false;
     std::vector<Buf*> all() {
         return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_tmp, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
                 &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &lut8, &lut16, &rois, &plane_stats};
@@ -210,7 +214,8 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.edges_i = (uint32_t*)h->edges_i.p;
     // class plane: colour images on the vector paths only (16-pixel groups in k_hist_rgb, 16-column groups in k_mask)
     j.passes_event = h->passes_event;
-    j.plane_stats = (C == 3) ? (uint32_t*)h->plane_stats.p : nullptr;
+    j.plane_stats = (C == 3 || dtype == LFA_U16) ? (uint32_t*)h->plane_stats.p : nullptr;
+    j.hist_abs = (dtype == LFA_U16 && !(h->debug_flags & 8) && (h->u16_one_pass || (h->debug_flags & 16))) ? 1 : 0;
     j.bins = (C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4))) ? (uint8_t*)h->bins.p : nullptr;
     j.maskT = (uint64_t*)h->maskT.p;
     j.col_cnt = (uint32_t*)h->col_cnt.p;
@@ -253,9 +258,10 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (max_strips < 1 || max_strips > 1024) return fail(LFA_ERR_ARG, "max_strips must be in [1,1024]");
     LFA_ON_DEVICE(h->device);
     if ((rc = ensure_workspace(h, n, H, W, C, dtype, L, max_strips))) return rc;
-    if (C == 3 && h->plane_pending && hipEventQuery(h->plane_event) == hipSuccess) {      // an earlier call's counters have arrived
+    if (h->plane_pending && hipEventQuery(h->plane_event) == hipSuccess) {                // an earlier call's counters have arrived
         h->plane_pending = false;
         if (h->plane_host[1]) h->plane_on = 2u * h->plane_host[0] >= h->plane_host[1];
+        if (h->plane_host[3]) h->u16_one_pass = h->plane_host[2] < (uint32_t)lfa::kLdsBinsU16;
     }
     lfa::Job j = make_job(h, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
     lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
@@ -264,8 +270,8 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     LFA_HIP(lfa::launch_mask(j, s));
     LFA_HIP(lfa::launch_label(j, s));
     LFA_HIP(lfa::launch_regions(j, o, s));
-    if (C == 3 && !h->plane_pending) {
-        LFA_HIP(hipMemcpyAsync(h->plane_host, h->plane_stats.p, 8, hipMemcpyDeviceToHost, s));
+    if (j.plane_stats && !h->plane_pending) {
+        LFA_HIP(hipMemcpyAsync(h->plane_host, h->plane_stats.p, 16, hipMemcpyDeviceToHost, s));
         LFA_HIP(hipEventRecord(h->plane_event, s));
         h->plane_pending = true;
     }
@@ -312,12 +318,12 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         return fail(LFA_ERR_HIP, "uploading gamma tables failed");
     }
     if ((rc = ensure_workspace(h, max_batch, max_h, max_w, max_c, LFA_U16, 10, 64))) { lfa_destroy(h); return rc; }
-    if ((rc = ensure(h->plane_stats, 8))) { lfa_destroy(h); return rc; }
-    if (hipHostMalloc((void**)&h->plane_host, 8, hipHostMallocDefault) != hipSuccess) {
+    if ((rc = ensure(h->plane_stats, 16))) { lfa_destroy(h); return rc; }
+    if (hipHostMalloc((void**)&h->plane_host, 16, hipHostMallocDefault) != hipSuccess) {
         h->plane_host = nullptr; lfa_destroy(h);
         return fail(LFA_ERR_NOMEM, "hipHostMalloc failed");
     }
-    h->plane_host[0] = h->plane_host[1] = 0u;
+    h->plane_host[0] = h->plane_host[1] = h->plane_host[2] = h->plane_host[3] = 0u;
     if (hipEventCreateWithFlags(&h->plane_event, hipEventDisableTiming) != hipSuccess) {
         h->plane_event = nullptr; lfa_destroy(h);
         return fail(LFA_ERR_HIP, "hipEventCreate failed");

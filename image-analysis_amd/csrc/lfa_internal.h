@@ -10,6 +10,7 @@
 namespace lfa {
 
 constexpr int kHistBinsU16 = 65536;
+constexpr int kLdsBinsU16 = 16384;        // k_hist_u16 counts this many consecutive values in LDS, the rest with global atomics
 constexpr int kEdges = 257;              // 256 float bins -> 257 edges
 constexpr int kEdgesI = 264;             // integer edge record per image: 257 thresholds + the three words below
 constexpr int kEdgesI_Crit = 257;        // != 0: some histogram edge is critical -> float64 histogram path
@@ -43,8 +44,11 @@ struct Job {
     double* edges_g;         // [n][257]  gray-space bin edges (colour path)
     uint32_t* edges_i;       // [n][264]  the same as integer thresholds on G = 2125*b0 + 7154*b1 + 721*b2 (k_threshold.hip)
     hipEvent_t passes_event; // recorded on the launch stream right after the histogram pass (lfa_stream_wait_passes); may be null
-    uint32_t* plane_stats;   // [2]  colour images of this call whose mask could be decided from the class plane / colour images seen
-                             //      (k_otsu_rgb counts; the host reads them later to decide whether the next call writes the plane)
+    uint32_t* plane_stats;   // [4]  [0] colour images of this call whose mask could be decided from the class plane, [1] colour images
+                             //      seen (k_otsu_rgb counts), [2] largest pixel value of the call's uint16 images, [3] uint16 images
+                             //      seen (k_otsu_int); the host reads them later to choose the next call's paths
+    int32_t hist_abs;        // uint16: the histogram is indexed by the pixel value itself and k_otsu_int finds the occupied range
+                             //         from it -- no min/max pass (values >= kLdsBinsU16 go to global atomics)
     uint8_t* bins;           // [n][H*W/2]  colour path: class plane, (histogram bin >> 4) of every pixel in 4 bits, written by
                              //             k_hist_rgb and read by k_mask instead of the image (0.5 byte per pixel instead of 3);
                              //             null = not used

@@ -129,7 +129,9 @@ int lfa_set_gray_variant(LfaHandle h, int variant);
  * re-reads the image, as it does for unaligned images).
  * bit2: the class plane is written and used however many pixels share the threshold's class (by default an image uses
  * it only below 1/2048 of its pixels, because each of them sends the mask pass back to the image, and a handle stops
- * writing the plane while fewer than half of the colour images of its last completed call could use it). */
+ * writing the plane while fewer than half of the colour images of its last completed call could use it).
+ * bit3: uint16 images always take the min/max pass before the histogram pass; bit4: never (by default a handle drops the
+ * min/max pass once its last completed uint16 call held no value of 16384 or more). */
 int lfa_set_debug_flags(LfaHandle h, int flags);
 
 /* ---- detect: detect_lateral_flow_tests(image, line_length) -- detection.py:31-94 ----------------------------------- */
@@ -207,6 +209,7 @@ int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H,
 #define LFA_DBG_TABLE   3   /* int32 K*5 : minr,minc,maxr,maxc,area per label (regionprops, detection.py:71-73) */
 #define LFA_DBG_HIST    4   /* uint32 nb : histogram counts (nb = 256 colour / uint8, xmax-xmin+1 uint16; input domain) */
 #define LFA_DBG_PLANE   5   /* int32 1   : 1 if the mask of this (colour) image was decided from the class plane, else 0 */
+#define LFA_DBG_ONEPASS 6   /* int32 1   : 1 if the last call took the one-pass uint16 histogram (no min/max pass), else 0 */
 
 /* Rasterise intermediate `what` of image `image_index` of the LAST detect/analyze call into `out` (device). */
 int lfa_debug_fetch(LfaHandle h, int image_index, int what, void* out, int64_t out_bytes, void* stream);

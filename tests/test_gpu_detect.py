@@ -207,6 +207,60 @@ def test_class_plane_is_chosen_per_image_and_per_call(capi):
         eng.close()
 
 
+def _u16_frame(rng, top, H=160, W=256):
+    g = rng.integers(top // 40, top // 8, size=(H, W)).astype(np.uint16)
+    for c0 in (30, 110, 190):
+        g[15:140, c0:c0 + 12] = rng.integers(top // 2, top, size=(125, 12))
+    return g
+
+
+@pytest.mark.parametrize("top", [4095, 16383, 16384, 65535])
+def test_uint16_one_pass_and_two_pass_histograms_agree(capi, eng, top):
+    """uint16 frames: the histogram indexed by pixel value (no min/max pass; values >= 16384 counted with global atomics)
+    and the two-pass form (min/max first, bins relative to the minimum) give the oracle's threshold, mask, labels, strips."""
+    rng = np.random.default_rng(top)
+    img = _u16_frame(rng, top)
+    img[0, 0] = top                                                 # the largest value is present
+    for flags in (8, 16):
+        eng.set_debug_flags(flags)
+        try:
+            check_detect(capi, eng, img, 60, 10)
+            assert eng.debug_one_pass() == (flags == 16)
+        finally:
+            eng.set_debug_flags(0)
+    const = np.full((64, 64), 1234, np.uint16)                      # constant frame: one occupied bin
+    for flags in (8, 16):
+        eng.set_debug_flags(flags)
+        try:
+            check_detect(capi, eng, const, 10, 3)
+        finally:
+            eng.set_debug_flags(0)
+
+
+def test_uint16_one_pass_is_chosen_per_call(capi):
+    """A handle drops the min/max pass once its last completed uint16 call held no value of 16384 or more, and takes it
+    up again after a call that did."""
+    rng = np.random.default_rng(5)
+    eng = capi.Engine(device=0, max_h=160, max_w=256, max_batch=2)
+    try:
+        low = np.stack([_u16_frame(rng, 4095) for _ in range(2)])
+        high = np.stack([_u16_frame(rng, 60000) for _ in range(2)])
+
+        def run(batch):
+            res = eng.detect(batch, 60, 10)
+            for i in range(len(batch)):
+                check_detect(capi, eng, batch[i], 60, 10, batch_index=i, res=res)
+            return eng.debug_one_pass()
+        assert run(low) is False            # nothing known yet: two passes
+        assert run(low) is True             # the last call stayed below 16384
+        assert run(high) is True            # still the one-pass form: exact, the high values go through global atomics
+        assert run(high) is False           # ... and the handle has learnt
+        assert run(low) is False
+        assert run(low) is True
+    finally:
+        eng.close()
+
+
 def test_colour_extreme_values(capi, eng):
     """black and saturated pixels, all 256 levels per channel, strongly different channels"""
     rng = np.random.default_rng(77)
