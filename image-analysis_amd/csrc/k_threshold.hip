@@ -446,9 +446,9 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
     const uint32_t* gh = j.hist + (int64_t)img * j.hist_stride;
     const int t = threadIdx.x;
     __shared__ int s_lo, s_hi;
-    __shared__ unsigned long long s_w[256], s_s[256];
-    __shared__ double s_bv[256];
-    __shared__ int s_bi[256];
+    __shared__ unsigned long long s_w[4], s_s[4];
+    __shared__ double s_bv[4];
+    __shared__ int s_bi[4];
     int xmin, xmax;
     const bool abs_hist = j.dtype == LFA_U8 || j.hist_abs;      // bins are pixel values
     if (j.dtype == LFA_U8) {
@@ -508,22 +508,21 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
         const unsigned long long c = gh[base_bin + b];
         w += c; s += c * (unsigned long long)lut(xmin + b);
     }
-    s_w[t] = w; s_s[t] = s;
-    __syncthreads();
-    if (t == 0) {                                   // exclusive scan over the 256 segment sums
-        unsigned long long aw = 0, as = 0;
-        for (int k = 0; k < 256; ++k) {
-            const unsigned long long cw = s_w[k], cs = s_s[k];
-            s_w[k] = aw; s_s[k] = as; aw += cw; as += cs;
-        }
-        s_lo = 0;   // reuse as scratch
+    // exclusive scan over the 256 segment sums: inclusive scan inside each wave, then the four wave totals
+    unsigned long long iw = w, is = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long uw = __shfl_up(iw, o), us = __shfl_up(is, o);
+        if ((t & 63) >= o) { iw += uw; is += us; }
     }
+    if ((t & 63) == 63) { s_w[t >> 6] = iw; s_s[t >> 6] = is; }
     __syncthreads();
-    __shared__ unsigned long long s_totw, s_tots;
-    if (t == 255) { s_totw = s_w[255] + w; s_tots = s_s[255] + s; }
-    __syncthreads();
-    const unsigned long long totw = s_totw, tots = s_tots;
-    unsigned long long cw = s_w[t], cs = s_s[t];
+    unsigned long long totw = 0, tots = 0, cw = iw - w, cs = is - s;
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long aw = s_w[k], as = s_s[k];
+        totw += aw; tots += as;
+        if (k < (t >> 6)) { cw += aw; cs += as; }
+    }
     for (int b = b0; b < b1; ++b) {
         const unsigned long long c = gh[base_bin + b];
         const int v = lut(xmin + b);
@@ -539,12 +538,21 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
         }
     }
     }
-    s_bv[t] = bv; s_bi[t] = bi;
+    // first maximum over all candidates: bins ascend with the thread index, so ties go to the lower bin
+    if (bi < 0) { bv = -1.0; bi = 0x7fffffff; }                 // (variances are >= 0)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double v2 = __shfl_xor(bv, o);
+        const int i2 = __shfl_xor(bi, o);
+        if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+    }
+    if ((t & 63) == 0) { s_bv[t >> 6] = bv; s_bi[t >> 6] = bi; }
     __syncthreads();
     if (t == 0) {
-        double best = -1.0; int idx = -1;
-        for (int k = 0; k < 256; ++k)
-            if (s_bi[k] >= 0 && (idx < 0 || s_bv[k] > best)) { best = s_bv[k]; idx = s_bi[k]; }
+        double best = s_bv[0]; int idx = s_bi[0];
+        for (int k = 1; k < 4; ++k)
+            if (s_bv[k] > best || (s_bv[k] == best && s_bi[k] < idx)) { best = s_bv[k]; idx = s_bi[k]; }
+        if (idx == 0x7fffffff) idx = -1;
         if (idx < 0) {                               // gamma table flat over the whole range: all gamma values equal
             inf->all_equal = 1; inf->v_thr = lut(xmin); inf->x_thr = 0x7fffffff; inf->otsu_bin = -1;
         } else {
