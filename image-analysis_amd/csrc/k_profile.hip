@@ -396,7 +396,11 @@ hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const i
     if (n_rois <= 0) return hipSuccess;
     // the analyze path only ever profiles windows of int(.6h) - int(.25h) <= 0.35*H + 1 rows: size the LDS for that
     int max_len = stride;
-    if (counts) { const int wl = (int)(0.35 * j.H) + 2; if (wl < max_len) max_len = wl; }
+    if (counts) {
+        const int wl = (int)(0.35 * j.H) + 2;
+        if (wl < max_len) max_len = wl;
+        if (j.win_hint > 0 && j.win_hint < max_len) max_len = j.win_hint;     // what the last call needed; longer windows fall back
+    }
     // row sums: one wave per ROI (all 64 lanes keep loads in flight), float64 accumulators in LDS
     {
         const int ls = (max_len + 1) & ~1;

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
             r.r0 = a.minr + (int)((double)h * .25); r.r1 = a.minr + (int)((double)h * .6);
             r.c0 = a.minc + (int)((double)w * .3);  r.c1 = a.minc + (int)((double)w * .7);
             rois[rank] = r;
+            if (j.plane_stats && r.r1 > r.r0) atomicMax(&j.plane_stats[4], (uint32_t)(r.r1 - r.r0));
             j.slot_rs_off[(int64_t)img * j.max_strips + rank] = a.rs_off;
         }
     }

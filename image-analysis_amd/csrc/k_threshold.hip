@@ -26,7 +26,7 @@ namespace lfa {
 __global__ __launch_bounds__(256) void k_init_info(Job j) {
     const int img = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    if (t == 0 && img == 0 && j.plane_stats) { j.plane_stats[0] = 0u; j.plane_stats[1] = 0u; j.plane_stats[2] = 0u; j.plane_stats[3] = 0u; }
+    if (t < 8 && img == 0 && j.plane_stats) j.plane_stats[t] = 0u;
     if (t == 0) {
         LfaImageInfo z;
         z.xmin = 0x7fffffff; z.xmax = -1; z.v_thr = 0; z.x_thr = 0x7fffffff;

@@ -110,6 +110,7 @@ struct LfaContext {
     // pass less over the image); worth it while the values stay below the LDS table of k_hist_u16 (camera data of 12-14
     // bits).  Chosen from the largest value of the last completed uint16 call, which travels with the counters above.
     bool u16_one_pass = false;
+    int win_hint = 0;                      // longest analysis window of the last completed call (rows), 0 = unknown
     std::vector<Buf*> all() {
         return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_tmp, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
                 &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &lut8, &lut16, &rois, &plane_stats};
@@ -214,7 +215,8 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.edges_i = (uint32_t*)h->edges_i.p;
     // class plane: colour images on the vector paths only (16-pixel groups in k_hist_rgb, 16-column groups in k_mask)
     j.passes_event = h->passes_event;
-    j.plane_stats = (C == 3 || dtype == LFA_U16) ? (uint32_t*)h->plane_stats.p : nullptr;
+    j.plane_stats = (uint32_t*)h->plane_stats.p;
+    j.win_hint = (h->debug_flags & 32) ? 0 : h->win_hint;
     j.hist_abs = (dtype == LFA_U16 && !(h->debug_flags & 8) && (h->u16_one_pass || (h->debug_flags & 16))) ? 1 : 0;
     j.bins = (C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4))) ? (uint8_t*)h->bins.p : nullptr;
     j.maskT = (uint64_t*)h->maskT.p;
@@ -262,6 +264,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         h->plane_pending = false;
         if (h->plane_host[1]) h->plane_on = 2u * h->plane_host[0] >= h->plane_host[1];
         if (h->plane_host[3]) h->u16_one_pass = h->plane_host[2] < (uint32_t)lfa::kLdsBinsU16;
+        if (h->plane_host[4]) h->win_hint = (int)h->plane_host[4];
     }
     lfa::Job j = make_job(h, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
     lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
@@ -271,7 +274,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     LFA_HIP(lfa::launch_label(j, s));
     LFA_HIP(lfa::launch_regions(j, o, s));
     if (j.plane_stats && !h->plane_pending) {
-        LFA_HIP(hipMemcpyAsync(h->plane_host, h->plane_stats.p, 16, hipMemcpyDeviceToHost, s));
+        LFA_HIP(hipMemcpyAsync(h->plane_host, h->plane_stats.p, 32, hipMemcpyDeviceToHost, s));
         LFA_HIP(hipEventRecord(h->plane_event, s));
         h->plane_pending = true;
     }
@@ -318,12 +321,12 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         return fail(LFA_ERR_HIP, "uploading gamma tables failed");
     }
     if ((rc = ensure_workspace(h, max_batch, max_h, max_w, max_c, LFA_U16, 10, 64))) { lfa_destroy(h); return rc; }
-    if ((rc = ensure(h->plane_stats, 16))) { lfa_destroy(h); return rc; }
-    if (hipHostMalloc((void**)&h->plane_host, 16, hipHostMallocDefault) != hipSuccess) {
+    if ((rc = ensure(h->plane_stats, 32))) { lfa_destroy(h); return rc; }
+    if (hipHostMalloc((void**)&h->plane_host, 32, hipHostMallocDefault) != hipSuccess) {
         h->plane_host = nullptr; lfa_destroy(h);
         return fail(LFA_ERR_NOMEM, "hipHostMalloc failed");
     }
-    h->plane_host[0] = h->plane_host[1] = h->plane_host[2] = h->plane_host[3] = 0u;
+    for (int k = 0; k < 8; ++k) h->plane_host[k] = 0u;
     if (hipEventCreateWithFlags(&h->plane_event, hipEventDisableTiming) != hipSuccess) {
         h->plane_event = nullptr; lfa_destroy(h);
         return fail(LFA_ERR_HIP, "hipEventCreate failed");

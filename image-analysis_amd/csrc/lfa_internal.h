@@ -44,9 +44,11 @@ struct Job {
     double* edges_g;         // [n][257]  gray-space bin edges (colour path)
     uint32_t* edges_i;       // [n][264]  the same as integer thresholds on G = 2125*b0 + 7154*b1 + 721*b2 (k_threshold.hip)
     hipEvent_t passes_event; // recorded on the launch stream right after the histogram pass (lfa_stream_wait_passes); may be null
-    uint32_t* plane_stats;   // [4]  [0] colour images of this call whose mask could be decided from the class plane, [1] colour images
+    uint32_t* plane_stats;   // [8]  [4] longest analysis window of the call in rows (k_finalize); [0] colour images of this call whose mask could be decided from the class plane, [1] colour images
                              //      seen (k_otsu_rgb counts), [2] largest pixel value of the call's uint16 images, [3] uint16 images
                              //      seen (k_otsu_int); the host reads them later to choose the next call's paths
+    int32_t win_hint;        // > 0: longest analysis window (rows) of the handle's last completed call -- sizes the LDS profile slots of
+                             //      k_profile / k_peaks below the worst case 0.35*H (longer windows take the global-memory path)
     int32_t hist_abs;        // uint16: the histogram is indexed by the pixel value itself and k_otsu_int finds the occupied range
                              //         from it -- no min/max pass (values >= kLdsBinsU16 go to global atomics)
     uint8_t* bins;           // [n][H*W/2]  colour path: class plane, (histogram bin >> 4) of every pixel in 4 bits, written by

@@ -131,7 +131,9 @@ int lfa_set_gray_variant(LfaHandle h, int variant);
  * it only below 1/2048 of its pixels, because each of them sends the mask pass back to the image, and a handle stops
  * writing the plane while fewer than half of the colour images of its last completed call could use it).
  * bit3: uint16 images always take the min/max pass before the histogram pass; bit4: never (by default a handle drops the
- * min/max pass once its last completed uint16 call held no value of 16384 or more). */
+ * min/max pass once its last completed uint16 call held no value of 16384 or more).
+ * bit5: the LDS profile slots of lfa_analyze_batch are sized for the worst case (by default for the longest analysis window
+ * of the handle's last completed call; longer windows take the global-memory path). */
 int lfa_set_debug_flags(LfaHandle h, int flags);
 
 /* ---- detect: detect_lateral_flow_tests(image, line_length) -- detection.py:31-94 ----------------------------------- */

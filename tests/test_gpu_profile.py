@@ -136,6 +136,26 @@ def _check_analyze(eng, imgs, mm_r, mm_c):
     return total, info
 
 
+def test_analyze_window_length_hint_and_its_fallback():
+    """lfa_analyze_batch sizes its LDS profile slots for the longest window of the handle's last completed call.  Windows
+    that turn out longer (here: min_maxr tripled on the next call) take the global-memory path; results stay the oracle's."""
+    import torch
+    import image_analysis_amd._capi as capi
+    from image_analysis_amd.synth import synth_rgb
+    imgs = np.stack([synth_rgb(640, 512, 6, 500 + i) for i in range(2)])
+    eng = capi.Engine(device=0, max_h=640, max_w=512, max_batch=2)
+    try:
+        for mm_r in (120, 120, 600, 600, 120):                     # short windows, then 3-5x longer ones than the hint, then short again
+            n, _ = _check_analyze(eng, imgs, mm_r, 12)
+            torch.cuda.synchronize()
+            assert n >= 4
+        eng.set_debug_flags(32)                                    # worst-case slots
+        _check_analyze(eng, imgs, 600, 12)
+        eng.set_debug_flags(0)
+    finally:
+        eng.close()
+
+
 def test_analyze_with_the_largest_strip_list():
     """max_strips = 1024 is the API's upper limit: k_finalize's accepted / kept lists (dynamic LDS) are then at their largest."""
     import image_analysis_amd._capi as capi
