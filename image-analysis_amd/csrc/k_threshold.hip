@@ -251,8 +251,20 @@ __global__ __launch_bounds__(1024) void k_hist_u16(Job j) {
     const int xmin = j.hist_abs ? 0 : j.info[img].xmin, xmax = j.hist_abs ? 65535 : j.info[img].xmax;
     if (xmax <= xmin) return;                       // constant image: no histogram needed (all-equal shortcut)
     const int nb = xmax - xmin + 1;
-    const int nlds = nb < kLdsBinsU16 ? nb : kLdsBinsU16;
-    for (int k = threadIdx.x; k < nlds; k += blockDim.x) sh[k] = 0;
+    // The first nl bins are counted in LDS, the rest with global atomics.  nl is a power of two and the LDS words left
+    // over hold copies of the table (lane l uses copy l & (copies-1)): pixels of a frame crowd on a few grey levels, and
+    // lanes adding to the same word serialise.  Two-pass form: nl covers the occupied range; one-pass form: nl covers
+    // the largest value of the handle's last call (Job::u16_lds_bins), larger values still count exactly, only slower.
+    int want = j.hist_abs ? j.u16_lds_bins : nb;
+    want = want < 256 ? 256 : (want > kLdsBinsU16 ? kLdsBinsU16 : want);
+    int lg = 8;
+    while ((1 << lg) < want) ++lg;
+    const int nl = 1 << lg;                         // 256 .. 16384
+    const int cshift = 14 - lg;                     // copies = 16384 / nl
+    const uint32_t cmask = (1u << cshift) - 1u;
+    const uint32_t cp = threadIdx.x & cmask;
+    const int nlds = nb < nl ? nb : nl;
+    for (int k = threadIdx.x; k < kLdsBinsU16; k += blockDim.x) sh[k] = 0;
     __syncthreads();
     const uint16_t* base = (const uint16_t*)(j.images + (int64_t)img * j.img_bytes);
     uint32_t* gh = j.hist + (int64_t)img * j.hist_stride;
@@ -261,6 +273,10 @@ __global__ __launch_bounds__(1024) void k_hist_u16(Job j) {
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     int64_t done = 0;
     int olo = 0x7fffffff, ohi = -1;                              // occupied range seen by this thread (bins; one-pass form)
+    auto count = [&](int a) {
+        if (a < nl) atomicAdd(&sh[((uint32_t)a << cshift) | cp], 1u);
+        else { atomicAdd(&gh[a], 1u); ohi = max(ohi, a); olo = min(olo, a); }
+    };
     if (j.aligned16) {
         const int64_t ng = npix >> 3;
         const uint4* v = (const uint4*)base;
@@ -268,21 +284,15 @@ __global__ __launch_bounds__(1024) void k_hist_u16(Job j) {
             const uint4 q = v[g];
             const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int a = (int)(w[k] & 0xffffu) - xmin, b = (int)(w[k] >> 16) - xmin;
-                if (a < kLdsBinsU16) atomicAdd(&sh[a], 1u); else { atomicAdd(&gh[a], 1u); ohi = max(ohi, a); olo = min(olo, a); }
-                if (b < kLdsBinsU16) atomicAdd(&sh[b], 1u); else { atomicAdd(&gh[b], 1u); ohi = max(ohi, b); olo = min(olo, b); }
-            }
+            for (int k = 0; k < 4; ++k) { count((int)(w[k] & 0xffffu) - xmin); count((int)(w[k] >> 16) - xmin); }
         }
         done = ng << 3;
     }
-    for (int64_t p = done + tid; p < npix; p += nth) {
-        const int a = (int)base[p] - xmin;
-        if (a < kLdsBinsU16) atomicAdd(&sh[a], 1u); else { atomicAdd(&gh[a], 1u); ohi = max(ohi, a); olo = min(olo, a); }
-    }
+    for (int64_t p = done + tid; p < npix; p += nth) count((int)base[p] - xmin);
     __syncthreads();
     for (int k = threadIdx.x; k < nlds; k += blockDim.x) {
-        const uint32_t c = sh[k];
+        uint32_t c = 0;
+        for (uint32_t q = 0; q <= cmask; ++q) c += sh[((uint32_t)k << cshift) | ((q + threadIdx.x) & cmask)];   // rotated: spreads the lanes over the banks
         if (c) { atomicAdd(&gh[k], c); ohi = max(ohi, k); olo = min(olo, k); }
     }
     if (j.hist_abs) {                                            // one-pass form: the occupied range falls out of the flush

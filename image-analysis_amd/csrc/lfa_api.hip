@@ -110,6 +110,7 @@ struct LfaContext {
     // pass less over the image); worth it while the values stay below the LDS table of k_hist_u16 (camera data of 12-14
     // bits).  Chosen from the largest value of the last completed uint16 call, which travels with the counters above.
     bool u16_one_pass = false;
+    int u16_max = 65535;                   // largest uint16 value of the last completed uint16 call
     int win_hint = 0;                      // longest analysis window of the last completed call (rows), 0 = unknown
     std::vector<Buf*> all() {
         return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_tmp, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
@@ -217,6 +218,7 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.passes_event = h->passes_event;
     j.plane_stats = (uint32_t*)h->plane_stats.p;
     j.win_hint = (h->debug_flags & 32) ? 0 : h->win_hint;
+    j.u16_lds_bins = (h->debug_flags & 16) ? lfa::kLdsBinsU16 : h->u16_max + 1;
     j.hist_abs = (dtype == LFA_U16 && !(h->debug_flags & 8) && (h->u16_one_pass || (h->debug_flags & 16))) ? 1 : 0;
     j.bins = (C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4))) ? (uint8_t*)h->bins.p : nullptr;
     j.maskT = (uint64_t*)h->maskT.p;
@@ -263,7 +265,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (h->plane_pending && hipEventQuery(h->plane_event) == hipSuccess) {                // an earlier call's counters have arrived
         h->plane_pending = false;
         if (h->plane_host[1]) h->plane_on = 2u * h->plane_host[0] >= h->plane_host[1];
-        if (h->plane_host[3]) h->u16_one_pass = h->plane_host[2] < (uint32_t)lfa::kLdsBinsU16;
+        if (h->plane_host[3]) { h->u16_max = (int)h->plane_host[2]; h->u16_one_pass = h->plane_host[2] < (uint32_t)lfa::kLdsBinsU16; }
         if (h->plane_host[4]) h->win_hint = (int)h->plane_host[4];
     }
     lfa::Job j = make_job(h, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);

@@ -49,6 +49,7 @@ struct Job {
                              //      seen (k_otsu_int); the host reads them later to choose the next call's paths
     int32_t win_hint;        // > 0: longest analysis window (rows) of the handle's last completed call -- sizes the LDS profile slots of
                              //      k_profile / k_peaks below the worst case 0.35*H (longer windows take the global-memory path)
+    int32_t u16_lds_bins;    // one-pass uint16 histogram: values below this are counted in LDS (largest value of the last call + 1)
     int32_t hist_abs;        // uint16: the histogram is indexed by the pixel value itself and k_otsu_int finds the occupied range
                              //         from it -- no min/max pass (values >= kLdsBinsU16 go to global atomics)
     uint8_t* bins;           // [n][H*W/2]  colour path: class plane, (histogram bin >> 4) of every pixel in 4 bits, written by
