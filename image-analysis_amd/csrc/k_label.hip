@@ -71,9 +71,6 @@ __global__ __launch_bounds__(256) void k_runs_count(Job j) {
 // cycles, and the root of a finished component is the run holding its raster-first pixel.  parent[] is read with
 // agent-scope relaxed atomic loads while other workgroups link (a stale "I am a root" only makes the CAS fail and hand
 // back the current parent); the CAS is the only writer.
-__device__ inline uint32_t run_key(const Job& j, int64_t rbase, int i) {
-    return (j.run_se[rbase + i] & 0xffffu) * (uint32_t)j.W + (uint32_t)j.run_col[rbase + i];
-}
 
 __device__ inline int uf_find_live(int* parent, int i) {
     for (;;) {
@@ -83,19 +80,20 @@ __device__ inline int uf_find_live(int* parent, int i) {
     }
 }
 
-__device__ inline void uf_unite(const Job& j, int64_t rbase, int* parent, int a, int b) {
+template <class KeyFn>   // key(i) = row_start * W + col of run i
+__device__ inline void uf_unite(int* parent, int a, int b, const KeyFn& key) {
     for (;;) {
         a = uf_find_live(parent, a);
         b = uf_find_live(parent, b);
         if (a == b) return;
-        if (run_key(j, rbase, a) < run_key(j, rbase, b)) { const int t = a; a = b; b = t; }   // a: larger key
+        if (key(a) < key(b)) { const int t = a; a = b; b = t; }   // a: larger key
         const int old = atomicCAS(&parent[a], a, b);
         if (old == a) return;
         a = old;
     }
 }
 
-constexpr int kLdsRuns = 16384;      // union-find parents of up to this many runs live in LDS (64 KiB)
+constexpr int kLdsRuns = 8192;       // parents, row ranges and columns of up to this many runs live in LDS (32 + 32 + 16 KiB)
 
 // Connected components of one image in ONE 1024-thread block: union-find over the runs, flatten + fold area / bbox into
 // the roots, number the roots.  Images have a few hundred to a few thousand runs (the strips' columns plus noise that
@@ -110,8 +108,11 @@ constexpr int kLdsRuns = 16384;      // union-find parents of up to this many ru
 //            of the same row further left
 __global__ __launch_bounds__(1024) void k_components(Job j) {
     __shared__ int lds_parent[kLdsRuns];
+    __shared__ uint32_t lds_se[kLdsRuns];                      // copies of run_se / run_col: every phase below reads them several
+    __shared__ uint16_t lds_col[kLdsRuns];                     // times, through dependent chains (binary search, find, ranking)
     __shared__ uint32_t wsum[16];
     __shared__ int s_label00;
+    __shared__ uint32_t s_nroots;                              // roots found so far (one LDS add per wave and round, not one global add per root)
     __shared__ int s_wcnt[16], s_base;
     const int img = blockIdx.x;
     const int H = j.H, W = j.W;
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
                 const int64_t i = rbase + run + k;
                 j.run_se[i] = se;
                 j.run_col[i] = (uint16_t)c;
+                if (run + k < (uint32_t)kLdsRuns) { lds_se[run + k] = se; lds_col[run + k] = (uint16_t)c; }
                 j.parent[i] = (int)(run + k);
                 j.area[i] = e - s + 1;
                 int4 bb; bb.x = s; bb.y = c; bb.z = e + 1; bb.w = c + 1;
@@ -165,25 +167,27 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
     uint32_t* rowcnt = j.rowcnt + (int64_t)img * (H + 1);
     uint32_t* rowpos = j.rowpos + (int64_t)img * (H + 1);
     if (in_lds) for (int i = t; i < nr; i += 1024) lds_parent[i] = i;
-    if (t == 0) s_label00 = 0;
+    if (t == 0) { s_label00 = 0; s_nroots = 0; }
     __syncthreads();
+    auto SE = [&](int i) -> uint32_t { return in_lds ? lds_se[i] : j.run_se[rbase + i]; };
+    auto COL = [&](int i) -> int { return in_lds ? (int)lds_col[i] : (int)j.run_col[rbase + i]; };
 
     // ---- union
     for (int i = t; i < nr; i += 1024) {
-        const int c = j.run_col[rbase + i];
+        const int c = COL(i);
         if (c + 1 >= j.W) continue;
-        const uint32_t se = j.run_se[rbase + i];
+        const uint32_t se = SE(i);
         const int a = (int)(se & 0xffffu), b = (int)(se >> 16);
         int lo = (int)off[c + 1];
         const int end = min((int)off[c + 2], j.run_cap);
         int hi = end;
         while (lo < hi) {                                   // first neighbour whose end >= a - 1
             const int mid = (lo + hi) >> 1;
-            if ((int)(j.run_se[rbase + mid] >> 16) >= a - 1) hi = mid; else lo = mid + 1;
+            if ((int)(SE(mid) >> 16) >= a - 1) hi = mid; else lo = mid + 1;
         }
         for (int q = lo; q < end; ++q) {
-            if ((int)(j.run_se[rbase + q] & 0xffffu) > b + 1) break;
-            uf_unite(j, rbase, parent, i, q);
+            if ((int)(SE(q) & 0xffffu) > b + 1) break;
+            uf_unite(parent, i, q, [&](int r) { return (SE(r) & 0xffffu) * (uint32_t)j.W + (uint32_t)COL(r); });
         }
     }
     __threadfence_block();
@@ -196,13 +200,22 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
         int r = i, s = 0, e = -1, c = 0;
         if (active) {
             r = uf_find_live(parent, i);
-            const uint32_t se = j.run_se[rbase + i];
-            s = (int)(se & 0xffffu); e = (int)(se >> 16); c = j.run_col[rbase + i];
+            const uint32_t se = SE(i);
+            s = (int)(se & 0xffffu); e = (int)(se >> 16); c = COL(i);
             if (r != i) __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // shortens later finds
             if (in_lds) j.parent[rbase + i] = r;                     // the global copy is what lfa_debug_fetch paints from
-            if (r == i) {                                            // a root: its run starts at the component's raster-first pixel
-                atomicAdd(&rowcnt[s], 1u);
-                j.rootlist[rbase + atomicAdd(&rowcnt[H], 1u)] = i;
+        }
+        {                                                            // roots: their runs start at the components' raster-first pixels
+            const bool root = active && r == i;
+            const unsigned long long rb = __ballot(root);
+            if (rb) {
+                uint32_t base = 0;
+                if (lane == __ffsll(rb) - 1) base = atomicAdd(&s_nroots, (uint32_t)__popcll(rb));
+                base = __shfl(base, __ffsll(rb) - 1);
+                if (root) {
+                    atomicAdd(&rowcnt[s], 1u);
+                    j.rootlist[rbase + base + __popcll(rb & ((1ull << lane) - 1ull))] = i;
+                }
             }
         }
         const bool need = active && r != i;
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
     __syncthreads();
 
     // ---- rank
-    const int K = min((int)__hip_atomic_load(&rowcnt[H], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), j.run_cap);
+    const int K = min((int)s_nroots, j.run_cap);
     const int seg = (H + 1023) / 1024;
     const int r0 = min(H, t * seg), r1 = min(H, r0 + seg);
     uint32_t sum = 0;
@@ -247,20 +260,20 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
     __syncthreads();
     for (int q = t; q < K; q += 1024) {
         const int i = __hip_atomic_load(&j.rootlist[rbase + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int s = (int)(j.run_se[rbase + i] & 0xffffu);
+        const int s = (int)(SE(i) & 0xffffu);
         j.bucket[rbase + atomicAdd(&rowpos[s], 1u)] = i;
     }
     __threadfence_block();
     __syncthreads();
     for (int q = t; q < K; q += 1024) {
         const int i = __hip_atomic_load(&j.rootlist[rbase + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int s = (int)(j.run_se[rbase + i] & 0xffffu), c = j.run_col[rbase + i];
+        const int s = (int)(SE(i) & 0xffffu), c = COL(i);
         const uint32_t lo = __hip_atomic_load(&rowcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t hi = __hip_atomic_load(&rowpos[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t before = 0;
         for (uint32_t b = lo; b < hi; ++b) {
             const int o = __hip_atomic_load(&j.bucket[rbase + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            before += (j.run_col[rbase + o] < c) ? 1u : 0u;
+            before += (COL(o) < c) ? 1u : 0u;
         }
         const int lab = (int)(lo + before) + 1;
         j.root_of_label[rbase + lab - 1] = i;
