@@ -34,25 +34,27 @@ def bench_u16(B=1024, CH=256, pool=8):
     p = torch.from_numpy(pool_np.view(np.uint8).reshape(pool, -1)).to(dev)
     batch = p[torch.arange(B, device=dev) % pool].contiguous()
     ms, stride = 64, int(H * .6) + 1
-    engs = [capi.Engine(device=0, max_h=H, max_w=W, max_c=1, max_batch=CH) for _ in range(2)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    NS = int(__import__("os").environ.get("LFA_STREAMS", "2"))
+    engs = [capi.Engine(device=0, max_h=H, max_w=W, max_c=1, max_batch=CH) for _ in range(NS)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     strips = capi.dev_bytes(B * ms * 24, dev); counts = torch.zeros(B, dtype=torch.int32, device=dev)
     info = capi.dev_bytes(B * 104, dev); rois = capi.dev_bytes(B * ms * 20, dev)
     prof = torch.empty(B * ms * stride, dtype=torch.float64, device=dev); peaks = capi.dev_bytes(B * ms * 40, dev)
     ib = H * W * 2
     torch.cuda.synchronize()
 
-    def step(ns=2):
+    def step(ns=NS):
         for ci, b0 in enumerate(range(0, B, CH)):
             capi._check(capi.lib.lfa_analyze_batch(engs[ci % ns]._h, batch.data_ptr() + b0 * ib, capi.LFA_U16, CH, H, W, 1, 1020, 51, 10,
                         strips.data_ptr() + b0 * ms * 24, ms, counts.data_ptr() + b0 * 4, info.data_ptr() + b0 * 104,
                         rois.data_ptr() + b0 * ms * 20, prof.data_ptr() + b0 * ms * stride * 8, stride,
                         peaks.data_ptr() + b0 * ms * 40, C.c_void_p(streams[ci % ns].cuda_stream)))
+    step(); torch.cuda.synchronize()                            # the handles settle their choices (one-pass histogram, LDS slots)
     dt = timed(step)
     engs[0].timing("*"); step(1); torch.cuda.synchronize(); kt = engs[0].timing_read(); engs[0].timing(None)
     ns = int(counts.sum().item())
     inf = capi.from_device(info, capi.INFO_DT, B)
-    print(json.dumps({"config": "configs[2] 2048x2048 uint16 frames", "frames": B, "ms_per_step": round(dt * 1e3, 3),
+    print(json.dumps({"config": "configs[2] 2048x2048 uint16 frames", "streams": NS, "chunk": CH, "frames": B, "ms_per_step": round(dt * 1e3, 3),
                       "frames_per_s": round(B / dt, 1), "strips_per_s": round(ns / dt, 1), "labels_mean": float(inf["n_labels"].mean()),
                       "e2e_frac_hbm": round(B / dt * ib / 8e12, 4),
                       "kernel_ms_one_stream": {k: round(v[0], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}}))
