@@ -11,6 +11,13 @@
 
 namespace lfa {
 
+typedef uint32_t lfa_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 nt_load8(const uint8_t* p) {   // read once, by this kernel only
+    const lfa_u32x2 v = __builtin_nontemporal_load((const lfa_u32x2*)p);
+    return make_uint2(v.x, v.y);
+}
+
+
 // MODE 0: uint8 2-D, 1: uint16 2-D, 2: uint8 colour.  VEC: 16 pixels per lane per row through 16-byte loads.
 template <int MODE, int V, bool VEC>
 __global__ __launch_bounds__(256) void k_mask(Job j) {
@@ -60,7 +67,7 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
             uint2 av[32];
 #pragma unroll
             for (int i = 0; i < 32; ++i)                                  // 32 rows are requested together
-                av[i] = (jq * 32 + i < rows) ? *(const uint2*)(bp + (int64_t)(jq * 32 + i) * rowb) : make_uint2(0u, 0u);
+                av[i] = (jq * 32 + i < rows) ? nt_load8(bp + (int64_t)(jq * 32 + i) * rowb) : make_uint2(0u, 0u);
 #pragma unroll
             for (int jh = 0; jh < 4; ++jh) {
                 const int jb = jq * 4 + jh;
