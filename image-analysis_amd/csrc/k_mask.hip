@@ -35,21 +35,24 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
     // colour: integer form of the compare (k_threshold.hip g_threshold) unless the threshold is critical
     uint32_t G_thr = 0;
     bool integer_path = false;
-    if (MODE == 2) {
+    if (MODE != 0) {
         const uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
-        G_thr = eg[kEdgesI_MaskThr];
-        integer_path = eg[kEdgesI_MaskCrit] == 0;
+        if (MODE == 2) {
+            G_thr = eg[kEdgesI_MaskThr];
+            integer_path = eg[kEdgesI_MaskCrit] == 0;
+        }
         if (VEC && j.bins && eg[kEdgesI_Bins]) {
             // The class plane k_hist_rgb wrote (bin >> 4 of every pixel, 4 bits each) decides every pixel whose class
             // differs from the class q of the Otsu bin: class > q: set, class < q: clear -- half a byte per pixel
             // instead of three.  A pixel of class q is settled by the exact compare on the image itself.
+            // uint16 frames: the same with the sixteen value ranges of k_hist_u16 and the class of x_thr (two bytes saved).
             const int ncg = W >> 4;
             const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
             if (item >= (int64_t)j.HB * ncg) return;
             const int rb = (int)(item / ncg), cg = (int)(item % ncg);
             const int r0 = rb * 64;
             const int rows = min(64, H - r0);
-            const uint32_t q = (uint32_t)inf.otsu_bin >> 4;
+            const uint32_t q = (MODE == 2) ? (uint32_t)inf.otsu_bin >> 4 : eg[kEdgesI_Class];
             const uint32_t q8 = q * 0x11111111u;
             const uint8_t* bp = j.bins + (((int64_t)img * H * W + (int64_t)r0 * W) >> 1) + (int64_t)cg * 8;
             const int64_t rowb = (int64_t)W >> 1;
@@ -126,12 +129,15 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
                 const int r = __ffsll((unsigned long long)eqrows) - 1;
                 eqrows &= eqrows - 1;
                 const uint2 a = *(const uint2*)(bp + (int64_t)r * rowb);
-                const uint8_t* px = base + ((int64_t)(r0 + r) * W + (int64_t)cg * 16) * 3;
+                const uint8_t* px = base + ((int64_t)(r0 + r) * W + (int64_t)cg * 16) * (MODE == 2 ? 3 : 2);
                 unsigned long long nib = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
 #pragma nounroll
-                for (int k = 0; k < 16; ++k, nib >>= 4)
-                    if ((uint32_t)(nib & 15ull) == q && (2125u * px[3 * k] + 7154u * px[3 * k + 1] + 721u * px[3 * k + 2]) >= G_thr)
-                        atomicOr((unsigned long long*)&o[k], 1ull << r);
+                for (int k = 0; k < 16; ++k, nib >>= 4) {
+                    if ((uint32_t)(nib & 15ull) != q) continue;
+                    const bool set = (MODE == 2) ? (2125u * px[3 * k] + 7154u * px[3 * k + 1] + 721u * px[3 * k + 2]) >= G_thr
+                                                 : (int)((const uint16_t*)px)[k] > x_thr;
+                    if (set) atomicOr((unsigned long long*)&o[k], 1ull << r);
+                }
             }
             return;
         }

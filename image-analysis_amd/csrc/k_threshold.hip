@@ -26,7 +26,7 @@ namespace lfa {
 __global__ __launch_bounds__(256) void k_init_info(Job j) {
     const int img = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    if (t < 8 && img == 0 && j.plane_stats) j.plane_stats[t] = 0u;
+    if (t < kStatsWords && img == 0 && j.plane_stats) j.plane_stats[t] = 0u;
     if (t == 0) {
         LfaImageInfo z;
         z.xmin = 0x7fffffff; z.xmax = -1; z.v_thr = 0; z.x_thr = 0x7fffffff;
@@ -278,15 +278,30 @@ __global__ __launch_bounds__(1024) void k_hist_u16(Job j) {
         else { atomicAdd(&gh[a], 1u); ohi = max(ohi, a); olo = min(olo, a); }
     };
     if (j.aligned16) {
-        const int64_t ng = npix >> 3;
+        const int64_t ng = npix >> 4;                            // 16 pixels = 32 bytes per lane and step
         const uint4* v = (const uint4*)base;
+        // class plane (Job::u16_plane, one-pass form only): 4 bits per pixel, pixel p in nibble p & 7 of dword p >> 3 --
+        // the layout k_mask reads for colour images; 8 bytes per lane and step
+        uint2* plane = j.u16_plane ? (uint2*)(j.bins + (((int64_t)img * npix) >> 1)) : nullptr;
+        const uint32_t pa = (uint32_t)j.u16_pa;
+        const int ps = j.u16_ps;
         for (int64_t g = tid; g < ng; g += nth) {
-            const uint4 q = v[g];
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            const uint4 q0 = v[2 * g], q1 = v[2 * g + 1];
+            const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { count((int)(w[k] & 0xffffu) - xmin); count((int)(w[k] >> 16) - xmin); }
+            for (int k = 0; k < 8; ++k) { count((int)(w[k] & 0xffffu) - xmin); count((int)(w[k] >> 16) - xmin); }
+            if (plane) {
+                uint32_t cls[2] = {0u, 0u};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t x = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                    const uint32_t c = min((x > pa ? x - pa : 0u) >> ps, 15u);
+                    cls[k >> 3] |= c << (4 * (k & 7));
+                }
+                vm_store8(plane + g, cls[0], cls[1]);
+            }
         }
-        done = ng << 3;
+        done = ng << 4;
     }
     for (int64_t p = done + tid; p < npix; p += nth) count((int)base[p] - xmin);
     __syncthreads();
@@ -476,8 +491,9 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
     const int base_bin = abs_hist ? xmin : 0;                   // two-pass uint16 histogram is stored relative to xmin
     const int nb = xmax - xmin + 1;
     auto lut = [&](int x) -> int { return (j.dtype == LFA_U8) ? (int)j.lut8[x] : (int)j.lut16[x]; };
+    uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
     if (nb <= 1) {
-        if (t == 0) { inf->all_equal = 1; inf->v_thr = lut(xmin); inf->x_thr = 0x7fffffff; inf->otsu_bin = -1; }
+        if (t == 0) { inf->all_equal = 1; inf->v_thr = lut(xmin); inf->x_thr = 0x7fffffff; inf->otsu_bin = -1; eg[kEdgesI_Bins] = 0u; }
         return;
     }
     const int seg = (nb + 255) / 256;
@@ -563,11 +579,30 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
         for (int k = 1; k < 4; ++k)
             if (s_bv[k] > best || (s_bv[k] == best && s_bi[k] < idx)) { best = s_bv[k]; idx = s_bi[k]; }
         if (idx == 0x7fffffff) idx = -1;
+        eg[kEdgesI_Bins] = 0u;
         if (idx < 0) {                               // gamma table flat over the whole range: all gamma values equal
             inf->all_equal = 1; inf->v_thr = lut(xmin); inf->x_thr = 0x7fffffff; inf->otsu_bin = -1;
         } else {
             const int v = lut(xmin + idx);
-            inf->v_thr = v; inf->x_thr = xmin + idx; inf->otsu_bin = v - lut(xmin);
+            const int x_thr = xmin + idx;
+            inf->v_thr = v; inf->x_thr = x_thr; inf->otsu_bin = v - lut(xmin);
+            if (j.dtype == LFA_U16 && j.plane_stats) { atomicAdd(&j.plane_stats[5], (uint32_t)x_thr); atomicAdd(&j.plane_stats[8], 1u); }
+            if (j.dtype == LFA_U16 && j.hist_abs && j.u16_ps > 0) {
+                // Class plane (k_hist_u16): the classes above the threshold's class q are set, those below are clear, and only
+                // the pixels of class q itself are compared in k_mask on the image.  Worth it when those are few: q is one
+                // of the narrow classes and holds at most 1/2048 of the pixels (debug flag 4 lifts both conditions).
+                const int q = min(max(x_thr - j.u16_pa, 0) >> j.u16_ps, 15);
+                bool could = false;
+                if (q >= 1 && q <= 14) {
+                    const int c0 = j.u16_pa + (q << j.u16_ps), c1 = min(c0 + (1 << j.u16_ps), 65536);
+                    unsigned long long in_class = 0;
+                    for (int x = c0; x < c1; ++x) in_class += gh[x];
+                    could = in_class * 2048ull <= (unsigned long long)((int64_t)j.H * j.W);
+                }
+                if (j.plane_stats) { if (could) atomicAdd(&j.plane_stats[6], 1u); atomicAdd(&j.plane_stats[7], 1u); }
+                eg[kEdgesI_Class] = (uint32_t)q;
+                eg[kEdgesI_Bins] = (j.u16_plane && (could || (j.debug_flags & 4))) ? 1u : 0u;
+            }
         }
     }
 }

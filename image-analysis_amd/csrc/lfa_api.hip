@@ -103,7 +103,7 @@ struct LfaContext {
     // set up: while fewer than half of the images could use it, the histogram pass does not write the plane at all
     // (photo-like inputs: 0.59 -> 0.42 ms per 256 images).  Results do not depend on the choice.
     Buf plane_stats;
-    uint32_t* plane_host = nullptr;        // pinned, 2 words
+    uint32_t* plane_host = nullptr;        // pinned, kStatsWords words
     hipEvent_t plane_event = nullptr;
     bool plane_pending = false, plane_on = true;
     // uint16 images: the histogram pass needs no min/max pass before it when the bins are the pixel values themselves (one
@@ -111,6 +111,10 @@ struct LfaContext {
     // bits).  Chosen from the largest value of the last completed uint16 call, which travels with the counters above.
     bool u16_one_pass = false;
     int u16_max = 65535;                   // largest uint16 value of the last completed uint16 call
+    // uint16 class plane (k_hist_u16 / k_mask): sixteen value ranges, narrow around the mean threshold of the last completed
+    // uint16 call; written while at least half of that call's frames could use it (judged on the ranges that call had)
+    bool u16_have_pred = false, u16_plane_on = true, pending_had_pred = false;
+    int u16_thr_mean = 0;
     int win_hint = 0;                      // longest analysis window of the last completed call (rows), 0 = unknown
     std::vector<Buf*> all() {
         return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_tmp, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
@@ -158,7 +162,7 @@ int ensure_workspace(LfaContext* h, int n, int H, int W, int C, int dtype, int L
     }
     if ((rc = ensure(h->edges, N * lfa::kEdges * 8))) return rc;
     if ((rc = ensure(h->edges_i, N * lfa::kEdgesI * 4))) return rc;
-    if (C == 3 && (rc = ensure(h->bins, N * (((size_t)H * W + 1) / 2)))) return rc;
+    if ((C == 3 || dtype == LFA_U16) && (rc = ensure(h->bins, N * (((size_t)H * W + 1) / 2)))) return rc;
     if ((rc = ensure(h->maskT, N * HB * W * 8))) return rc;
     if ((rc = ensure(h->col_cnt, N * (W + 1) * 4))) return rc;
     if ((rc = ensure(h->run_tmp, N * cap * 4))) return rc;
@@ -220,7 +224,16 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.win_hint = (h->debug_flags & 32) ? 0 : h->win_hint;
     j.u16_lds_bins = (h->debug_flags & 16) ? lfa::kLdsBinsU16 : h->u16_max + 1;
     j.hist_abs = (dtype == LFA_U16 && !(h->debug_flags & 8) && (h->u16_one_pass || (h->debug_flags & 16))) ? 1 : 0;
-    j.bins = (C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4))) ? (uint8_t*)h->bins.p : nullptr;
+    if (dtype == LFA_U16 && C == 1 && j.hist_abs) {
+        // class width 16 / 32 / 64 values for frames of up to 12 / 13 / 14 bits, the fourteen narrow classes centred on the
+        // mean threshold of the last call
+        const int ps = h->u16_max < 4096 ? 4 : (h->u16_max < 8192 ? 5 : 6);
+        if (h->u16_have_pred) { j.u16_ps = ps; j.u16_pa = h->u16_thr_mean - (15 << ps) / 2; if (j.u16_pa < 0) j.u16_pa = 0; }
+        else if (h->debug_flags & 4) { j.u16_ps = ps; j.u16_pa = 0; }
+        j.u16_plane = (j.u16_ps > 0 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->u16_plane_on || (h->debug_flags & 4))) ? 1 : 0;
+    }
+    const bool rgb_plane = C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4));
+    j.bins = (j.u16_plane || rgb_plane) ? (uint8_t*)h->bins.p : nullptr;
     j.maskT = (uint64_t*)h->maskT.p;
     j.col_cnt = (uint32_t*)h->col_cnt.p;
     j.run_tmp = (uint32_t*)h->run_tmp.p;
@@ -267,6 +280,8 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         if (h->plane_host[1]) h->plane_on = 2u * h->plane_host[0] >= h->plane_host[1];
         if (h->plane_host[3]) { h->u16_max = (int)h->plane_host[2]; h->u16_one_pass = h->plane_host[2] < (uint32_t)lfa::kLdsBinsU16; }
         if (h->plane_host[4]) h->win_hint = (int)h->plane_host[4];
+        if (h->plane_host[8]) { h->u16_thr_mean = (int)(h->plane_host[5] / h->plane_host[8]); h->u16_have_pred = true; }
+        if (h->plane_host[7]) h->u16_plane_on = !h->pending_had_pred || 2u * h->plane_host[6] >= h->plane_host[7];
     }
     lfa::Job j = make_job(h, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
     lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
@@ -276,7 +291,8 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     LFA_HIP(lfa::launch_label(j, s));
     LFA_HIP(lfa::launch_regions(j, o, s));
     if (j.plane_stats && !h->plane_pending) {
-        LFA_HIP(hipMemcpyAsync(h->plane_host, h->plane_stats.p, 32, hipMemcpyDeviceToHost, s));
+        LFA_HIP(hipMemcpyAsync(h->plane_host, h->plane_stats.p, lfa::kStatsWords * 4, hipMemcpyDeviceToHost, s));
+        h->pending_had_pred = h->u16_have_pred;
         LFA_HIP(hipEventRecord(h->plane_event, s));
         h->plane_pending = true;
     }
@@ -323,12 +339,12 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         return fail(LFA_ERR_HIP, "uploading gamma tables failed");
     }
     if ((rc = ensure_workspace(h, max_batch, max_h, max_w, max_c, LFA_U16, 10, 64))) { lfa_destroy(h); return rc; }
-    if ((rc = ensure(h->plane_stats, 32))) { lfa_destroy(h); return rc; }
-    if (hipHostMalloc((void**)&h->plane_host, 32, hipHostMallocDefault) != hipSuccess) {
+    if ((rc = ensure(h->plane_stats, lfa::kStatsWords * 4))) { lfa_destroy(h); return rc; }
+    if (hipHostMalloc((void**)&h->plane_host, lfa::kStatsWords * 4, hipHostMallocDefault) != hipSuccess) {
         h->plane_host = nullptr; lfa_destroy(h);
         return fail(LFA_ERR_NOMEM, "hipHostMalloc failed");
     }
-    for (int k = 0; k < 8; ++k) h->plane_host[k] = 0u;
+    for (int k = 0; k < lfa::kStatsWords; ++k) h->plane_host[k] = 0u;
     if (hipEventCreateWithFlags(&h->plane_event, hipEventDisableTiming) != hipSuccess) {
         h->plane_event = nullptr; lfa_destroy(h);
         return fail(LFA_ERR_HIP, "hipEventCreate failed");

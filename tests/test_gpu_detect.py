@@ -261,6 +261,89 @@ def test_uint16_one_pass_is_chosen_per_call(capi):
         eng.close()
 
 
+def _u16_separated(rng, H=160, W=256, noise=False):
+    """dark background, a dozen pixels above it, and bright strips (noise=True: values all over the range)"""
+    if noise:
+        g = rng.integers(0, 4096, size=(H, W)).astype(np.uint16)
+    else:
+        g = rng.integers(90, 110, size=(H, W)).astype(np.uint16)
+        g[rng.integers(0, H, 12), rng.integers(0, W, 12)] = 150            # the threshold lands here, in a nearly empty range
+    for c0 in (30, 110, 190):
+        g[15:140, c0:c0 + 12] = rng.integers(2000, 3000, size=(125, 12))
+    return g
+
+
+@pytest.mark.parametrize("W", [256, 250])
+def test_uint16_class_plane_paths_agree(capi, W):
+    """uint16 frames, one-pass histogram: the mask decided from the 4-bit class plane (forced with debug flag 4: first
+    without a predicted threshold, so that nearly every pixel is of the threshold's class and takes the exact compare,
+    then with the classes centred on the last call's threshold) and the mask compared on the frame itself (flag 2) both
+    give the oracle's threshold, mask, labels and strips.  A width that is no multiple of 16 has no plane."""
+    rng = np.random.default_rng(21)
+    eng = capi.Engine(device=0, max_h=160, max_w=256, max_batch=3)
+    try:
+        batch = np.stack([_u16_separated(rng, W=W), _u16_frame(rng, 4095, W=W), _u16_separated(rng, W=W, noise=True)])
+        for flags in (16 | 4, 16 | 4, 16 | 4, 16 | 2, 16):
+            eng.set_debug_flags(flags)
+            res = eng.detect(batch, 60, 10)
+            for i in range(len(batch)):
+                check_detect(capi, eng, batch[i], 60, 10, batch_index=i, res=res)
+                if flags & 4:
+                    assert eng.debug_used_plane(i) == (W % 16 == 0)
+                if flags & 2:
+                    assert not eng.debug_used_plane(i)
+            eng.sync() if hasattr(eng, "sync") else None
+    finally:
+        eng.close()
+
+
+def test_uint16_class_plane_is_chosen_per_image_and_per_call(capi):
+    """The uint16 class plane needs the one-pass histogram and a threshold to centre its classes on (the mean of the
+    handle's last call).  Per image it is used when the threshold's class is narrow and nearly empty; per call it is
+    written while at least half of the last call's frames could use it.  The test carries a host model of those rules."""
+    rng = np.random.default_rng(22)
+    eng = capi.Engine(device=0, max_h=160, max_w=256, max_batch=2)
+    st = {"one_pass": False, "have_pred": False, "plane_on": True, "mean": 0, "max": 65535}
+    seen = set()
+    try:
+        sep = np.stack([_u16_separated(rng) for _ in range(2)])
+        noisy = np.stack([_u16_separated(rng, noise=True) for _ in range(2)])
+
+        def run(batch):
+            res = eng.detect(batch, 60, 10)
+            info = res[1]
+            for i in range(len(batch)):
+                check_detect(capi, eng, batch[i], 60, 10, batch_index=i, res=res)
+            used = [eng.debug_used_plane(i) for i in range(len(batch))]
+            ps = (4 if st["max"] < 4096 else 5 if st["max"] < 8192 else 6) if (st["one_pass"] and st["have_pred"]) else 0
+            pa = max(0, st["mean"] - (15 << ps) // 2)
+            coulds = []
+            for i in range(len(batch)):
+                x = int(info[i]["x_thr"])
+                q = min(max(x - pa, 0) >> ps, 15) if ps else 0
+                lo = pa + (q << ps)
+                n_in = int(((batch[i] >= lo) & (batch[i] < lo + (1 << ps))).sum()) if ps else 0
+                coulds.append(bool(ps and 1 <= q <= 14 and n_in * 2048 <= batch[i].size))
+            expect = [bool(ps and st["plane_on"] and c) for c in coulds]
+            assert used == expect, (used, expect, st, ps, pa)
+            seen.update(used)
+            if ps:
+                st["plane_on"] = 2 * sum(coulds) >= len(batch)
+            st["max"] = int(batch.max()); st["one_pass"] = st["max"] < 16384
+            st["mean"] = int(sum(int(info[i]["x_thr"]) for i in range(len(batch))) // len(batch)); st["have_pred"] = True
+            return used
+        assert run(sep) == [False, False]           # nothing known: two-pass histogram, no plane
+        assert run(sep) == [True, True]             # one pass, classes centred on the first call's thresholds
+        run(noisy)                                  # plane written, but the threshold's class is crowded: frames re-read
+        run(sep); run(sep); run(sep)
+        mixed = np.stack([sep[0], noisy[0]])
+        for _ in range(3):
+            run(mixed)
+        assert seen == {True, False}
+    finally:
+        eng.close()
+
+
 def test_colour_extreme_values(capi, eng):
     """black and saturated pixels, all 256 levels per channel, strongly different channels"""
     rng = np.random.default_rng(77)
