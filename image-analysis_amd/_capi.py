@@ -452,7 +452,7 @@ class Engine:
         return out.cpu().numpy().reshape(-1, 5)[:k]
 
     def debug_used_plane(self, image_index):
-        """True if the mask of colour image `image_index` of the last call was decided from the class plane (LFA_DBG_PLANE)."""
+        """True if the mask of image `image_index` of the last call was decided from the class plane (LFA_DBG_PLANE)."""
         torch = _torch()
         out = torch.zeros(1, dtype=torch.int32, device=self.device)
         _check(lib.lfa_debug_fetch(self._h, image_index, DBG_PLANE, out.data_ptr(), 4, current_stream_ptr(self.device)))

@@ -125,11 +125,13 @@ int lfa_set_gray_variant(LfaHandle h, int variant);
 
 /* Test hook (no counterpart in the reference).  bit0: colour images take the float64 compare path even when the exact
  * integer form of the thresholds is available (that path otherwise runs only for "critical" thresholds).
- * bit1: colour images do not use the per-pixel class plane between the histogram and the mask pass (the mask pass then
- * re-reads the image, as it does for unaligned images).
+ * bit1: images do not use the per-pixel class plane between the histogram and the mask pass (the mask pass then
+ * re-reads the image, as it does for unaligned images).  Colour images and, with the one-pass histogram, uint16 frames
+ * have such a plane.
  * bit2: the class plane is written and used however many pixels share the threshold's class (by default an image uses
  * it only below 1/2048 of its pixels, because each of them sends the mask pass back to the image, and a handle stops
- * writing the plane while fewer than half of the colour images of its last completed call could use it).
+ * writing the plane while fewer than half of the images of its last completed call could use it; uint16 frames also
+ * need a completed call before, whose mean threshold centres the classes -- with bit2 they start at value 0 without).
  * bit3: uint16 images always take the min/max pass before the histogram pass; bit4: never (by default a handle drops the
  * min/max pass once its last completed uint16 call held no value of 16384 or more).
  * bit5: the LDS profile slots of lfa_analyze_batch are sized for the worst case (by default for the longest analysis window
@@ -210,7 +212,7 @@ int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H,
 #define LFA_DBG_LABELS  2   /* int32 H*W : label(dilated)                     (detection.py:66) */
 #define LFA_DBG_TABLE   3   /* int32 K*5 : minr,minc,maxr,maxc,area per label (regionprops, detection.py:71-73) */
 #define LFA_DBG_HIST    4   /* uint32 nb : histogram counts (nb = 256 colour / uint8, xmax-xmin+1 uint16; input domain) */
-#define LFA_DBG_PLANE   5   /* int32 1   : 1 if the mask of this (colour) image was decided from the class plane, else 0 */
+#define LFA_DBG_PLANE   5   /* int32 1   : 1 if the mask of this image was decided from the class plane, else 0           */
 #define LFA_DBG_ONEPASS 6   /* int32 1   : 1 if the last call took the one-pass uint16 histogram (no min/max pass), else 0 */
 
 /* Rasterise intermediate `what` of image `image_index` of the LAST detect/analyze call into `out` (device). */

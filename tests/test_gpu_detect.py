@@ -96,6 +96,13 @@ def test_reference_sample_images(capi, golden_dir, key):
                 eng.set_debug_flags(flags)
                 check_detect(capi, eng, bgr, mm_r, mm_c)
             eng.set_debug_flags(0)
+        else:
+            # 16-bit frame: the same handle again -- one-pass histogram, then the class plane centred on its own
+            # threshold (default choice, then forced)
+            for flags in (0, 0, 4, 2):
+                eng.set_debug_flags(flags)
+                check_detect(capi, eng, img, mm_r, mm_c)
+            eng.set_debug_flags(0)
     finally:
         eng.close()
 
@@ -486,8 +493,8 @@ def test_random_small_images_against_oracle(capi, eng, seed):
         kind = rng.integers(0, 3)                                   # 0: uint8 2-D, 1: uint16 2-D, 2: colour
         H = int(rng.integers(1, 200)) if rng.random() < 0.8 else int(rng.integers(1, 12))
         W = int(rng.integers(1, 200)) if rng.random() < 0.8 else int(rng.integers(1, 12))
-        if kind == 2 and rng.random() < 0.5:
-            W = max(16, (W // 16) * 16)                             # the aligned colour path (class plane)
+        if kind != 0 and rng.random() < 0.5:
+            W = max(16, (W // 16) * 16)                             # the aligned paths (class plane)
         top = 255 if kind != 1 else int(rng.choice([255, 4095, 65535]))
         base = rng.integers(0, max(2, top // 3), size=(H, W))
         img = base.astype(np.int64)
@@ -507,7 +514,9 @@ def test_random_small_images_against_oracle(capi, eng, seed):
             arr = np.ascontiguousarray(np.stack(ch, axis=2).astype(np.uint8))
         L = int(rng.choice([1, 2, 5, 10, 10, 10, 17]))
         mm_r, mm_c = int(rng.integers(0, max(1, H))), int(rng.integers(0, max(1, W // 2 + 1)))
-        eng.set_debug_flags(int(rng.choice([0, 4])) if kind == 2 else 0)    # colour: default choice of the class plane, or forced
+        # colour: default choice of the class plane, or forced; uint16: default, or one-pass histogram with the plane forced
+        # (its classes centred on whatever threshold the shared handle met last), or the two-pass histogram
+        eng.set_debug_flags(int(rng.choice([0, 4])) if kind == 2 else (int(rng.choice([0, 16 | 4, 8])) if kind == 1 else 0))
         try:
             check_detect(capi, eng, arr, mm_r, mm_c, L)
         finally:
