@@ -43,8 +43,12 @@ def bench_u16(B=1024, CH=256, pool=8):
     ib = H * W * 2
     torch.cuda.synchronize()
 
+    STAGGER = int(__import__("os").environ.get("LFA_STAGGER", "0"))
+
     def step(ns=NS):
         for ci, b0 in enumerate(range(0, B, CH)):
+            if STAGGER and ns > 1:              # this chunk's passes start when the previous chunk's histogram pass is done
+                capi._check(capi.lib.lfa_stream_wait_passes(engs[(ci - 1) % ns]._h, C.c_void_p(streams[ci % ns].cuda_stream)))
             capi._check(capi.lib.lfa_analyze_batch(engs[ci % ns]._h, batch.data_ptr() + b0 * ib, capi.LFA_U16, CH, H, W, 1, 1020, 51, 10,
                         strips.data_ptr() + b0 * ms * 24, ms, counts.data_ptr() + b0 * 4, info.data_ptr() + b0 * 104,
                         rois.data_ptr() + b0 * ms * 20, prof.data_ptr() + b0 * ms * stride * 8, stride,
@@ -219,7 +223,7 @@ def bench_stream(n=1024, batch=64, pool=8):
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["u16", "rois", "gauss"]
-    if "u16" in what: bench_u16()
+    if "u16" in what: bench_u16(CH=int(__import__("os").environ.get("LFA_CHUNK", "256")))
     if "big" in what: bench_big()
     if "photo" in what: bench_photo()
     if "rois" in what: bench_rois()
