@@ -162,7 +162,9 @@ int ensure_workspace(LfaContext* h, int n, int H, int W, int C, int dtype, int L
     }
     if ((rc = ensure(h->edges, N * lfa::kEdges * 8))) return rc;
     if ((rc = ensure(h->edges_i, N * lfa::kEdgesI * 4))) return rc;
-    if ((C == 3 || dtype == LFA_U16) && (rc = ensure(h->bins, N * (((size_t)H * W + 1) / 2)))) return rc;
+    // class plane: colour images; uint16 frames once the handle takes the one-pass histogram (make_job)
+    const bool u16_plane_possible = dtype == LFA_U16 && C == 1 && !(h->debug_flags & 8) && (h->u16_one_pass || (h->debug_flags & 16));
+    if ((C == 3 || u16_plane_possible) && (rc = ensure(h->bins, N * (((size_t)H * W + 1) / 2)))) return rc;
     if ((rc = ensure(h->maskT, N * HB * W * 8))) return rc;
     if ((rc = ensure(h->col_cnt, N * (W + 1) * 4))) return rc;
     if ((rc = ensure(h->run_tmp, N * cap * 4))) return rc;
@@ -230,7 +232,7 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
         const int ps = h->u16_max < 4096 ? 4 : (h->u16_max < 8192 ? 5 : 6);
         if (h->u16_have_pred) { j.u16_ps = ps; j.u16_pa = h->u16_thr_mean - (15 << ps) / 2; if (j.u16_pa < 0) j.u16_pa = 0; }
         else if (h->debug_flags & 4) { j.u16_ps = ps; j.u16_pa = 0; }
-        j.u16_plane = (j.u16_ps > 0 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->u16_plane_on || (h->debug_flags & 4))) ? 1 : 0;
+        j.u16_plane = (j.u16_ps > 0 && h->bins.bytes >= (size_t)n * (((size_t)H * W + 1) / 2) && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->u16_plane_on || (h->debug_flags & 4))) ? 1 : 0;
     }
     const bool rgb_plane = C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4));
     j.bins = (j.u16_plane || rgb_plane) ? (uint8_t*)h->bins.p : nullptr;
@@ -274,7 +276,6 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (!out_strips || !out_counts) return fail(LFA_ERR_ARG, "null output pointer");
     if (max_strips < 1 || max_strips > 1024) return fail(LFA_ERR_ARG, "max_strips must be in [1,1024]");
     LFA_ON_DEVICE(h->device);
-    if ((rc = ensure_workspace(h, n, H, W, C, dtype, L, max_strips))) return rc;
     if (h->plane_pending && hipEventQuery(h->plane_event) == hipSuccess) {                // an earlier call's counters have arrived
         h->plane_pending = false;
         if (h->plane_host[1]) h->plane_on = 2u * h->plane_host[0] >= h->plane_host[1];
@@ -283,6 +284,8 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         if (h->plane_host[8]) { h->u16_thr_mean = (int)(h->plane_host[5] / h->plane_host[8]); h->u16_have_pred = true; }
         if (h->plane_host[7]) h->u16_plane_on = !h->pending_had_pred || 2u * h->plane_host[6] >= h->plane_host[7];
     }
+    // (after the counters: the workspace depends on the paths they select)
+    if ((rc = ensure_workspace(h, n, H, W, C, dtype, L, max_strips))) return rc;
     lfa::Job j = make_job(h, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
     lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
     TimerScope ts(h);
