@@ -27,10 +27,17 @@ def timed(fn, steps=10):
     return (time.perf_counter() - t0) / steps
 
 
-def bench_u16(B=1024, CH=256, pool=8):
-    """configs[2]: 2048x2048 uint16 frames, chunks alternating on two streams / handles like bench.py."""
+def bench_u16(B=1024, CH=256, pool=8, real=False):
+    """configs[2]: 2048x2048 uint16 frames, chunks alternating on two streams / handles like bench.py.
+    real=True: the reference's own 12-bit frame (tests/golden/excel2_frame.png, images/excel2.xlsx), rolled per pool slot."""
     H = W = 2048
-    pool_np = np.stack([synth.synth_u16(H, W, 40, 1234 + i) for i in range(pool)])
+    if real:
+        import os
+        from PIL import Image
+        f = np.array(Image.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "excel2_frame.png")))
+        pool_np = np.stack([np.ascontiguousarray(np.roll(f, (17 * i, 64 * i), (0, 1))) for i in range(pool)])
+    else:
+        pool_np = np.stack([synth.synth_u16(H, W, 40, 1234 + i) for i in range(pool)])
     p = torch.from_numpy(pool_np.view(np.uint8).reshape(pool, -1)).to(dev)
     batch = p[torch.arange(B, device=dev) % pool].contiguous()
     ms, stride = 64, int(H * .6) + 1
@@ -59,7 +66,7 @@ def bench_u16(B=1024, CH=256, pool=8):
     engs[0].timing("*"); step(1); torch.cuda.synchronize(); kt = engs[0].timing_read(); engs[0].timing(None)
     ns = int(counts.sum().item())
     inf = capi.from_device(info, capi.INFO_DT, B)
-    print(json.dumps({"config": "configs[2] 2048x2048 uint16 frames", "streams": NS, "chunk": CH, "frames": B, "ms_per_step": round(dt * 1e3, 3),
+    print(json.dumps({"config": "the reference's 12-bit frame excel2, 2048x2048 uint16" if real else "configs[2] 2048x2048 uint16 frames", "streams": NS, "chunk": CH, "frames": B, "ms_per_step": round(dt * 1e3, 3),
                       "frames_per_s": round(B / dt, 1), "strips_per_s": round(ns / dt, 1), "labels_mean": float(inf["n_labels"].mean()),
                       "e2e_frac_hbm": round(B / dt * ib / 8e12, 4),
                       "kernel_ms_one_stream": {k: round(v[0], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}}))
@@ -224,6 +231,7 @@ def bench_stream(n=1024, batch=64, pool=8):
 if __name__ == "__main__":
     what = sys.argv[1:] or ["u16", "rois", "gauss"]
     if "u16" in what: bench_u16(CH=int(__import__("os").environ.get("LFA_CHUNK", "256")))
+    if "u16real" in what: bench_u16(real=True)
     if "big" in what: bench_big()
     if "photo" in what: bench_photo()
     if "rois" in what: bench_rois()

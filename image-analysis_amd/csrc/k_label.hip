@@ -27,13 +27,39 @@ __device__ inline bool run_survives(int s, int e, int H, int L) {
     return eff >= L;
 }
 
+// 64 rows of one column: clear the runs that lie strictly inside the word (touching neither its first nor its last
+// row, nor -- through `above`, the rows past the image as ones -- the image's last row) and are shorter than L.  Such a
+// run fails run_survives whatever the neighbouring words hold, every other run is left whole, and the word's first and
+// last bit keep their values, so walking the result gives the same surviving runs.  A vertical opening inside the word,
+// bit-parallel: erosion with ones past bit 63, dilation with zeros below bit 0, windows doubled up to L.
+__device__ inline uint64_t drop_short_runs(uint64_t w, uint64_t above, int L) {
+    const uint64_t x = w | above;
+    const uint64_t nx = ~x;
+    if (nx == 0) return w;
+    uint64_t keep = x & ~(x + 1ull);                                     // the run from bit 0 upwards
+    const int lead = __clzll((long long)nx);                             // length of the run ending at bit 63
+    if (lead) keep |= ~0ull << (64 - lead);
+    if (L < 64) {
+        uint64_t e = x;
+        for (int have = 1; have < L;) { const int sh = min(have, L - have); e &= (e >> sh) | ~(~0ull >> sh); have += sh; }
+        for (int have = 1; have < L;) { const int sh = min(have, L - have); e |= e << sh; have += sh; }
+        keep |= e;
+    }
+    return w & keep;
+}
+
 // Walk column c of maskT top to bottom and call emit(start, end_inclusive) for every surviving run.
 template <class Emit>
 __device__ inline void column_runs(const uint64_t* colw, int HB, int H, int W, int L, const Emit& emit) {
     int start = -1;
     for (int rb = 0; rb < HB; ++rb) {
-        const uint64_t w = colw[(int64_t)rb * W];
+        uint64_t w = colw[(int64_t)rb * W];
         uint64_t t = w ^ ((w << 1) | (start >= 0 ? 1ull : 0ull));       // bit k set: mask changes between row k-1 and k
+        if (__popcll((unsigned long long)t) > 8) {                       // a noisy word: most of its runs are too short to survive
+            const int rem = H - rb * 64;
+            w = drop_short_runs(w, rem < 64 ? ~0ull << rem : 0ull, L);
+            t = w ^ ((w << 1) | (start >= 0 ? 1ull : 0ull));
+        }
         while (t) {
             const int b = __ffsll((unsigned long long)t) - 1;
             t &= t - 1;

@@ -484,6 +484,23 @@ def test_dropin_detect_returns_views_equal_to_oracle_crops(golden_dir):
         det.detect_lateral_flow_tests(np.zeros((8, 8, 4), np.uint8))
 
 
+@pytest.mark.parametrize("L", [1, 2, 3, 9, 10, 11, 17, 40, 63, 64, 65, 100])
+def test_opening_of_noisy_masks(capi, eng, L):
+    """Masks that are mostly noise (many short vertical runs per 64-row word: the run walk first drops, bit-parallel, the
+    runs that cannot survive) at several densities, heights around the word size and line lengths around it: opened
+    mask, labels and strips against scipy's erosion + dilation."""
+    rng = np.random.default_rng(300 + L)
+    for H in (63, 64, 65, 130, 200):
+        for density in (0.3, 0.5, 0.8, 0.95):
+            W = int(rng.choice([48, 67]))
+            img = np.where(rng.random((H, W)) < density, 200, 20).astype(np.uint8)
+            img[:, 5] = 200                                             # a full column, a run from the top, one to the bottom
+            img[: min(H, L // 2 + 1), 9] = 200
+            img[max(0, H - (L - 1) // 2 - 1):, 13] = 200
+            img[:, 8] = 20; img[:, 10] = 20; img[:, 12] = 20; img[:, 14] = 20
+            check_detect(capi, eng, img, int(rng.integers(0, H)), int(rng.integers(0, W // 2)), L)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_small_images_against_oracle(capi, eng, seed):
     """Seeded fuzz: random shapes (down to a few pixels), dtypes, blob layouts, thresholds of every kind, line lengths and

@@ -15,7 +15,7 @@ bash tools/pmc_passes.sh > gpurun_out/round_pmc.log 2>&1
 # one process per configuration: measured in one process after another configuration, configs[3] came out 14 % lower
 # (allocator / placement state left behind), alone it repeats within 0.3 %
 : > gpurun_out/round_secondary.log
-for c in u16 big photo rois gauss peaks stream; do
+for c in u16 u16real big photo rois gauss peaks stream; do
   timeout -k 10 200 python benchmarks_configs.py $c >> gpurun_out/round_secondary.log 2>&1
 done
 echo done
