@@ -67,7 +67,7 @@ def bench_u16(B=1024, CH=256, pool=8, real=False):
     ns = int(counts.sum().item())
     inf = capi.from_device(info, capi.INFO_DT, B)
     print(json.dumps({"config": "the reference's 12-bit frame excel2, 2048x2048 uint16" if real else "configs[2] 2048x2048 uint16 frames", "streams": NS, "chunk": CH, "frames": B, "ms_per_step": round(dt * 1e3, 3),
-                      "frames_per_s": round(B / dt, 1), "strips_per_s": round(ns / dt, 1), "labels_mean": float(inf["n_labels"].mean()),
+                      "frames_per_s": round(B / dt, 1), "strips_per_s": round(ns / dt, 1), "labels_mean": float(inf["n_labels"].mean()), "runs_mean": float(inf["n_runs"].mean()),
                       "e2e_frac_hbm": round(B / dt * ib / 8e12, 4),
                       "kernel_ms_one_stream": {k: round(v[0], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}}))
     for e in engs:

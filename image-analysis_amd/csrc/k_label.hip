@@ -119,6 +119,7 @@ __device__ inline void uf_unite(int* parent, int a, int b, const KeyFn& key) {
     }
 }
 
+constexpr int kLdsRows = 4096;       // images of up to this many rows count and rank their roots per row in LDS (2 x 16 KiB)
 constexpr int kLdsRuns = 8192;       // parents, row ranges and columns of up to this many runs live in LDS (32 + 32 + 16 KiB)
 
 // Connected components of one image in ONE 1024-thread block: union-find over the runs, flatten + fold area / bbox into
@@ -136,6 +137,9 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
     __shared__ int lds_parent[kLdsRuns];
     __shared__ uint32_t lds_se[kLdsRuns];                      // copies of run_se / run_col: every phase below reads them several
     __shared__ uint16_t lds_col[kLdsRuns];                     // times, through dependent chains (binary search, find, ranking)
+    __shared__ uint32_t lds_rows[2 * kLdsRows];                // first the columns' offsets into the run list (scan, move, union), then
+    uint32_t* const lds_rowcnt = lds_rows;                     // the roots per row of their first pixel -> offsets / fill cursors (rank)
+    uint32_t* const lds_rowpos = lds_rows + kLdsRows;
     __shared__ uint32_t wsum[16];
     __shared__ int s_label00;
     __shared__ uint32_t s_nroots;                              // roots found so far (one LDS add per wave and round, not one global add per root)
@@ -161,24 +165,16 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
         uint32_t run = inc - sum, total = 0;
         for (int q = 0; q < 16; ++q) { const uint32_t v = wsum[q]; total += v; if (q < wv) run += v; }
         const uint32_t cap = (uint32_t)j.run_cap;
+        // the offsets also go to LDS for the column search below and for the union phase
+        uint32_t* lds_off = lds_rows;
+        const bool off_in_lds = W + 1 <= 2 * kLdsRows;
         for (int c = c0; c < c1; ++c) {
             const uint32_t cnt = off[c];
             off[c] = run;
-            const uint32_t* tmp = j.run_tmp + rbase + (int64_t)c * j.runs_per_col;
-            for (uint32_t k = 0; k < cnt && run + k < cap; ++k) {
-                const uint32_t se = tmp[k];
-                const int s = (int)(se & 0xffffu), e = (int)(se >> 16);
-                const int64_t i = rbase + run + k;
-                j.run_se[i] = se;
-                j.run_col[i] = (uint16_t)c;
-                if (run + k < (uint32_t)kLdsRuns) { lds_se[run + k] = se; lds_col[run + k] = (uint16_t)c; }
-                j.parent[i] = (int)(run + k);
-                j.area[i] = e - s + 1;
-                int4 bb; bb.x = s; bb.y = c; bb.z = e + 1; bb.w = c + 1;
-                *(int4*)(j.bbox + i * 4) = bb;
-            }
+            if (off_in_lds) lds_off[c] = run;
             run += cnt;
         }
+        if (t == 0 && off_in_lds) lds_off[W] = total;
         if (t == 0) {
             off[W] = total;
             j.info[img].n_runs = (int)total;
@@ -187,11 +183,52 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
         __threadfence_block();
         __syncthreads();
     }
+    // One thread per run of the compact list (not per column: a noisy column parks dozens of runs, and every global load
+    // waits out the memory system's latency under the other stream's image passes): the run's column by binary search
+    // over the offsets, eight parked runs requested per thread before the first is stored.
+    const bool off_in_lds = W + 1 <= 2 * kLdsRows;
+    auto OFF = [&](int c) -> uint32_t { return off_in_lds ? lds_rows[c] : __hip_atomic_load(&off[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    {
+        const int total = min((int)__hip_atomic_load(&off[W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), j.run_cap);
+        for (int base = 0; base < total; base += 8 * 1024) {
+            uint32_t v[8]; int cc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 1024 + t;
+                v[u] = 0u; cc[u] = 0;
+                if (i < total) {
+                    int lo = 1, hi = W;                              // smallest c' with OFF(c') > i; the run's column is c' - 1
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (OFF(mid) > (uint32_t)i) hi = mid; else lo = mid + 1; }
+                    cc[u] = lo - 1;
+                    v[u] = j.run_tmp[rbase + (int64_t)cc[u] * j.runs_per_col + ((uint32_t)i - OFF(cc[u]))];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 1024 + t;
+                if (i < total) {
+                    const uint32_t se = v[u];
+                    const int c = cc[u], s0 = (int)(se & 0xffffu), e0 = (int)(se >> 16);
+                    const int64_t g = rbase + i;
+                    j.run_se[g] = se;
+                    j.run_col[g] = (uint16_t)c;
+                    if (i < kLdsRuns) { lds_se[i] = se; lds_col[i] = (uint16_t)c; }
+                    j.parent[g] = i;
+                    j.area[g] = e0 - s0 + 1;
+                    int4 bb; bb.x = s0; bb.y = c; bb.z = e0 + 1; bb.w = c + 1;
+                    *(int4*)(j.bbox + g * 4) = bb;
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
     const int nr = min((int)__hip_atomic_load(&off[W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), j.run_cap);
     const bool in_lds = nr <= kLdsRuns;
     int* parent = in_lds ? lds_parent : (j.parent + rbase);          // k_runs_fill initialised the global array to identity
-    uint32_t* rowcnt = j.rowcnt + (int64_t)img * (H + 1);
-    uint32_t* rowpos = j.rowpos + (int64_t)img * (H + 1);
+    const bool rows_in_lds = H <= kLdsRows;                          // else the global arrays (zeroed by k_init_info)
+    uint32_t* rowcnt = rows_in_lds ? lds_rowcnt : j.rowcnt + (int64_t)img * (H + 1);
+    uint32_t* rowpos = rows_in_lds ? lds_rowpos : j.rowpos + (int64_t)img * (H + 1);
     if (in_lds) for (int i = t; i < nr; i += 1024) lds_parent[i] = i;
     if (t == 0) { s_label00 = 0; s_nroots = 0; }
     __syncthreads();
@@ -204,8 +241,8 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
         if (c + 1 >= j.W) continue;
         const uint32_t se = SE(i);
         const int a = (int)(se & 0xffffu), b = (int)(se >> 16);
-        int lo = (int)off[c + 1];
-        const int end = min((int)off[c + 2], j.run_cap);
+        int lo = (int)OFF(c + 1);
+        const int end = min((int)OFF(c + 2), j.run_cap);
         int hi = end;
         while (lo < hi) {                                   // first neighbour whose end >= a - 1
             const int mid = (lo + hi) >> 1;
@@ -219,6 +256,10 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
     __threadfence_block();
     __syncthreads();
 
+    if (rows_in_lds) {                                               // the offsets' space becomes the row counts
+        for (int r = t; r < H; r += 1024) lds_rowcnt[r] = 0u;
+        __syncthreads();
+    }
     // ---- flatten
     for (int i0 = 0; i0 < nr; i0 += 1024) {
         const int i = i0 + t;
@@ -284,10 +325,11 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
     }
     __threadfence_block();
     __syncthreads();
+    int* bucket = in_lds ? lds_parent : j.bucket + rbase;            // the parents are flattened and copied out: their space is free
     for (int q = t; q < K; q += 1024) {
         const int i = __hip_atomic_load(&j.rootlist[rbase + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int s = (int)(SE(i) & 0xffffu);
-        j.bucket[rbase + atomicAdd(&rowpos[s], 1u)] = i;
+        bucket[atomicAdd(&rowpos[s], 1u)] = i;
     }
     __threadfence_block();
     __syncthreads();
@@ -298,7 +340,7 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
         const uint32_t hi = __hip_atomic_load(&rowpos[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t before = 0;
         for (uint32_t b = lo; b < hi; ++b) {
-            const int o = __hip_atomic_load(&j.bucket[rbase + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int o = __hip_atomic_load(&bucket[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             before += (COL(o) < c) ? 1u : 0u;
         }
         const int lab = (int)(lo + before) + 1;
