@@ -136,12 +136,12 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
     const int64_t cbase = (int64_t)img * j.cand_cap;
     const double bg = (double)inf->label00;                   // detection.py:67: the label id at (0,0)
     // The accept loop is sequential (a candidate is tested against everything accepted before it), but what it reads is
-    // not: the lanes fetch label, root, box and the region test of kStage candidates at once into LDS -- three dependent
+    // not: the lanes fetch label, root, box, area and the region test of kStage candidates at once into LDS -- three dependent
     // global loads per candidate that the loop would otherwise wait for one candidate at a time (images with hundreds
     // of candidates: 120 us -> a few) -- and the loop then runs on LDS.
     constexpr int kStage = 256;
     __shared__ int s_box[kStage][4];
-    __shared__ int s_root[kStage], s_lab[kStage];
+    __shared__ int s_area[kStage], s_rs[kStage], s_lab[kStage];
     __shared__ unsigned char s_ok[kStage];
     for (int c0 = 0; c0 < nc && !status; c0 += kStage) {
         const int m = min(kStage, nc - c0);
@@ -165,7 +165,8 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
                 ok = mean > bg;
             }
             s_box[k][0] = bx.minr; s_box[k][1] = bx.maxr; s_box[k][2] = bx.minc; s_box[k][3] = bx.maxc;
-            s_root[k] = root; s_lab[k] = lab; s_ok[k] = ok ? 1 : 0;
+            s_area[k] = j.area[rbase + root]; s_rs[k] = j.cand_rs_off[cbase + ci];     // for the accepted ones: fetched here, not one by one in the loop
+            s_lab[k] = lab; s_ok[k] = ok ? 1 : 0;
         }
         __syncthreads();
         for (int k = 0; k < m; ++k) {                          // uniform: every lane walks the same candidates
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
             if (na < cap) {
                 if (lane == 0) {
                     Acc a; a.minr = minr; a.maxr = maxr; a.minc = minc; a.maxc = maxc;
-                    a.area = j.area[rbase + s_root[k]]; a.label = s_lab[k]; a.rs_off = j.cand_rs_off[cbase + c0 + k];
+                    a.area = s_area[k]; a.label = s_lab[k]; a.rs_off = s_rs[k];
                     acc[na] = a;
                 }
                 __syncthreads();
