@@ -484,6 +484,26 @@ def test_dropin_detect_returns_views_equal_to_oracle_crops(golden_dir):
         det.detect_lateral_flow_tests(np.zeros((8, 8, 4), np.uint8))
 
 
+@pytest.mark.parametrize("shape", [(70, 8200), (4100, 48), (4100, 8200)])
+def test_very_wide_and_very_tall_images(capi, shape):
+    """k_components keeps the columns' offsets (W + 1 <= 8192) and the per-row root counts (H <= 4096) in LDS; wider and
+    taller images go through the global arrays instead -- same labels, boxes and strips."""
+    H, W = shape
+    rng = np.random.default_rng(H + W)
+    img = rng.integers(10, 60, size=(H, W)).astype(np.uint8)
+    for _ in range(40):                                             # vertical bars, some of them touching, some at the borders
+        r0, c0 = int(rng.integers(0, H - 12)), int(rng.integers(0, W - 4))
+        img[r0:r0 + int(rng.integers(12, max(13, H // 3))), c0:c0 + int(rng.integers(1, 4))] = int(rng.integers(180, 255))
+    img[:30, W - 2:] = 250
+    img[H - 30:, :2] = 250
+    img[rng.random((H, W)) < 0.001] = 255                           # salt: removed by the opening
+    eng = capi.Engine(device=0, max_h=H, max_w=W, max_batch=1)
+    try:
+        check_detect(capi, eng, img, H // 2, max(1, W // 40))
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("L", [1, 2, 3, 9, 10, 11, 17, 40, 63, 64, 65, 100])
 def test_opening_of_noisy_masks(capi, eng, L):
     """Masks that are mostly noise (many short vertical runs per 64-row word: the run walk first drops, bit-parallel, the
