@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
             const int rb = (int)(item / ncg), cg = (int)(item % ncg);
             const int r0 = rb * 64;
             const int rows = min(64, H - r0);
-            const uint32_t q = (MODE == 2) ? (uint32_t)inf.otsu_bin >> 4 : eg[kEdgesI_Class];
+            const uint32_t q = (MODE == 2) ? (uint32_t)inf.otsu_bin >> 4 : (eg[kEdgesI_Class] & 0xffu);
+            const bool settled = MODE == 1 && (eg[kEdgesI_Class] & 0x100u);     // class q is clear as a whole: no compare
             const uint32_t q8 = q * 0x11111111u;
             const uint8_t* bp = j.bins + (((int64_t)img * H * W + (int64_t)r0 * W) >> 1) + (int64_t)cg * 8;
             const int64_t rowb = (int64_t)W >> 1;
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
             // Pixels of class q: the exact compare on the image itself.  Rare (the classes around the Otsu bin are the
             // valley of the histogram), so this is a small rolled loop that ORs straight into the words just written
             // -- this lane's own words -- instead of 64 unrolled copies inside the loop above.
+            if (settled) eqrows = 0;
             while (eqrows) {
                 const int r = __ffsll((unsigned long long)eqrows) - 1;
                 eqrows &= eqrows - 1;

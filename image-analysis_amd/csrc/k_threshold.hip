@@ -586,21 +586,27 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
             const int v = lut(xmin + idx);
             const int x_thr = xmin + idx;
             inf->v_thr = v; inf->x_thr = x_thr; inf->otsu_bin = v - lut(xmin);
-            if (j.dtype == LFA_U16 && j.plane_stats) { atomicAdd(&j.plane_stats[5], (uint32_t)x_thr); atomicAdd(&j.plane_stats[8], 1u); }
-            if (j.dtype == LFA_U16 && j.hist_abs && j.u16_ps > 0) {
+            if (j.dtype == LFA_U16 && j.plane_stats) {
+                atomicAdd(&j.plane_stats[5], (uint32_t)x_thr); atomicAdd(&j.plane_stats[8], 1u);
+                atomicMax(&j.plane_stats[9], (uint32_t)(65535 - x_thr)); atomicMax(&j.plane_stats[10], (uint32_t)x_thr);
+            }
+            if (j.dtype == LFA_U16 && j.hist_abs && j.u16_pred) {
                 // Class plane (k_hist_u16): the classes above the threshold's class q are set, those below are clear, and only
-                // the pixels of class q itself are compared in k_mask on the image.  Worth it when those are few: q is one
-                // of the narrow classes and holds at most 1/2048 of the pixels (debug flag 4 lifts both conditions).
+                // the pixels of class q itself are compared in k_mask on the image.  If x_thr is the last value of its
+                // class, that class is clear as a whole and nothing is compared (classes one value wide: always).
+                // Otherwise worth it when those pixels are few: q is one of the narrow classes and holds at most 1/2048
+                // of the pixels (debug flag 4 lifts both conditions).
                 const int q = min(max(x_thr - j.u16_pa, 0) >> j.u16_ps, 15);
-                bool could = false;
-                if (q >= 1 && q <= 14) {
+                const bool settled = q <= 14 && x_thr == j.u16_pa + ((q + 1) << j.u16_ps) - 1;
+                bool could = settled;
+                if (!settled && q >= 1 && q <= 14) {
                     const int c0 = j.u16_pa + (q << j.u16_ps), c1 = min(c0 + (1 << j.u16_ps), 65536);
                     unsigned long long in_class = 0;
                     for (int x = c0; x < c1; ++x) in_class += gh[x];
                     could = in_class * 2048ull <= (unsigned long long)((int64_t)j.H * j.W);
                 }
                 if (j.plane_stats) { if (could) atomicAdd(&j.plane_stats[6], 1u); atomicAdd(&j.plane_stats[7], 1u); }
-                eg[kEdgesI_Class] = (uint32_t)q;
+                eg[kEdgesI_Class] = (uint32_t)q | (settled ? 0x100u : 0u);
                 eg[kEdgesI_Bins] = (j.u16_plane && (could || (j.debug_flags & 4))) ? 1u : 0u;
             }
         }

@@ -114,7 +114,7 @@ struct LfaContext {
     // uint16 class plane (k_hist_u16 / k_mask): sixteen value ranges, narrow around the mean threshold of the last completed
     // uint16 call; written while at least half of that call's frames could use it (judged on the ranges that call had)
     bool u16_have_pred = false, u16_plane_on = true, pending_had_pred = false;
-    int u16_thr_mean = 0;
+    int u16_thr_mean = 0, u16_thr_spread = 0;   // mean and (largest - smallest) threshold of that call
     int win_hint = 0;                      // longest analysis window of the last completed call (rows), 0 = unknown
     std::vector<Buf*> all() {
         return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_tmp, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
@@ -229,10 +229,16 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     if (dtype == LFA_U16 && C == 1 && j.hist_abs) {
         // class width 16 / 32 / 64 values for frames of up to 12 / 13 / 14 bits, the fourteen narrow classes centred on the
         // mean threshold of the last call
+        // -- or, when the thresholds of the last call lay within 10 values of each other (a series of one scene), one value
+        // per class: the threshold then is the last value of its class, the plane alone decides the mask (k_otsu_int)
         const int ps = h->u16_max < 4096 ? 4 : (h->u16_max < 8192 ? 5 : 6);
-        if (h->u16_have_pred) { j.u16_ps = ps; j.u16_pa = h->u16_thr_mean - (15 << ps) / 2; if (j.u16_pa < 0) j.u16_pa = 0; }
-        else if (h->debug_flags & 4) { j.u16_ps = ps; j.u16_pa = 0; }
-        j.u16_plane = (j.u16_ps > 0 && h->bins.bytes >= (size_t)n * (((size_t)H * W + 1) / 2) && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->u16_plane_on || (h->debug_flags & 4))) ? 1 : 0;
+        if (h->u16_have_pred) {
+            j.u16_pred = 1;
+            j.u16_ps = h->u16_thr_spread <= 10 ? 0 : ps;
+            j.u16_pa = h->u16_thr_mean - (j.u16_ps ? (15 << ps) / 2 : 7);
+            if (j.u16_pa < 0) j.u16_pa = 0;
+        } else if (h->debug_flags & 4) { j.u16_pred = 1; j.u16_ps = ps; j.u16_pa = 0; }
+        j.u16_plane = (j.u16_pred && h->bins.bytes >= (size_t)n * (((size_t)H * W + 1) / 2) && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->u16_plane_on || (h->debug_flags & 4))) ? 1 : 0;
     }
     const bool rgb_plane = C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4));
     j.bins = (j.u16_plane || rgb_plane) ? (uint8_t*)h->bins.p : nullptr;
@@ -281,7 +287,10 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         if (h->plane_host[1]) h->plane_on = 2u * h->plane_host[0] >= h->plane_host[1];
         if (h->plane_host[3]) { h->u16_max = (int)h->plane_host[2]; h->u16_one_pass = h->plane_host[2] < (uint32_t)lfa::kLdsBinsU16; }
         if (h->plane_host[4]) h->win_hint = (int)h->plane_host[4];
-        if (h->plane_host[8]) { h->u16_thr_mean = (int)(h->plane_host[5] / h->plane_host[8]); h->u16_have_pred = true; }
+        if (h->plane_host[8]) {
+            h->u16_thr_mean = (int)(h->plane_host[5] / h->plane_host[8]); h->u16_have_pred = true;
+            h->u16_thr_spread = (int)h->plane_host[10] - (65535 - (int)h->plane_host[9]);
+        }
         if (h->plane_host[7]) h->u16_plane_on = !h->pending_had_pred || 2u * h->plane_host[6] >= h->plane_host[7];
     }
     // (after the counters: the workspace depends on the paths they select)

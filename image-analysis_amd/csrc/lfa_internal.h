@@ -17,7 +17,8 @@ constexpr int kEdgesI_Crit = 257;        // != 0: some histogram edge is critica
 constexpr int kEdgesI_MaskThr = 258;     // integer form of the mask threshold
 constexpr int kEdgesI_MaskCrit = 259;    // != 0: mask threshold critical -> float64 mask path
 constexpr int kEdgesI_Bins = 260;        // != 0: the image's class plane (Job::bins) is valid and k_mask may use it
-constexpr int kEdgesI_Class = 261;       // uint16 class plane: the class of the image's threshold x_thr (k_otsu_int)
+constexpr int kEdgesI_Class = 261;       // uint16 class plane: the class q of the image's threshold x_thr; bit 8: x_thr is the last value
+                                         // of class q, so that class is clear as a whole and k_mask never looks at the frame (k_otsu_int)
 constexpr int kStatsWords = 12;          // Job::plane_stats
 constexpr int kAreaMin = 100;            // detection.py:81
 constexpr int kMaxCand = 1 << 20;
@@ -48,7 +49,7 @@ struct Job {
     hipEvent_t passes_event; // recorded on the launch stream right after the histogram pass (lfa_stream_wait_passes); may be null
     uint32_t* plane_stats;   // [kStatsWords]  [4] longest analysis window of the call in rows (k_finalize); [0] colour images of this call whose mask could be decided from the class plane, [1] colour images
                              //      seen (k_otsu_rgb counts), [2] largest pixel value of the call's uint16 images, [3] uint16 images
-                             //      seen (k_otsu_int); [5] sum and [8] number of the uint16 thresholds x_thr, [6] uint16 images whose
+                             //      seen (k_otsu_int); [5] sum, [8] number, [9] 65535 - smallest and [10] largest of the uint16 thresholds x_thr, [6] uint16 images whose
                              //      mask could be decided from the class plane around u16_pa, [7] images that test was made on;
                              //      the host reads them later to choose the next call's paths
     int32_t win_hint;        // > 0: longest analysis window (rows) of the handle's last completed call -- sizes the LDS profile slots of
@@ -57,7 +58,8 @@ struct Job {
     int32_t hist_abs;        // uint16: the histogram is indexed by the pixel value itself and k_otsu_int finds the occupied range
                              //         from it -- no min/max pass (values >= kLdsBinsU16 go to global atomics)
     int32_t u16_pa, u16_ps;  // uint16 class plane: class(v) = min(max(v - u16_pa, 0) >> u16_ps, 15) -- sixteen value ranges, narrow
-                             //         around the mean threshold of the handle's last call; u16_ps = 0: no prediction yet
+                             //         around the mean threshold of the handle's last call
+    int32_t u16_pred;        // u16_pa / u16_ps are set (a call has completed before, or debug flag 4)
     int32_t u16_plane;       // k_hist_u16 (one-pass form) writes that class of every pixel into `bins`
     uint8_t* bins;           // [n][H*W/2]  colour path: class plane, (histogram bin >> 4) of every pixel in 4 bits, written by
                              //             k_hist_rgb and read by k_mask instead of the image (0.5 byte per pixel instead of 3);

@@ -131,7 +131,8 @@ int lfa_set_gray_variant(LfaHandle h, int variant);
  * bit2: the class plane is written and used however many pixels share the threshold's class (by default an image uses
  * it only below 1/2048 of its pixels, because each of them sends the mask pass back to the image, and a handle stops
  * writing the plane while fewer than half of the images of its last completed call could use it; uint16 frames also
- * need a completed call before, whose mean threshold centres the classes -- with bit2 they start at value 0 without).
+ * need a completed call before, whose mean threshold centres the classes -- with bit2 they start at value 0 without;
+ * a frame whose threshold is the last value of its class needs no compare at all and always uses the plane).
  * bit3: uint16 images always take the min/max pass before the histogram pass; bit4: never (by default a handle drops the
  * min/max pass once its last completed uint16 call held no value of 16384 or more).
  * bit5: the LDS profile slots of lfa_analyze_batch are sized for the worst case (by default for the longest analysis window

@@ -310,7 +310,7 @@ def test_uint16_class_plane_is_chosen_per_image_and_per_call(capi):
     written while at least half of the last call's frames could use it.  The test carries a host model of those rules."""
     rng = np.random.default_rng(22)
     eng = capi.Engine(device=0, max_h=160, max_w=256, max_batch=2)
-    st = {"one_pass": False, "have_pred": False, "plane_on": True, "mean": 0, "max": 65535}
+    st = {"one_pass": False, "have_pred": False, "plane_on": True, "mean": 0, "max": 65535, "spread": 0}
     seen = set()
     try:
         sep = np.stack([_u16_separated(rng) for _ in range(2)])
@@ -322,22 +322,26 @@ def test_uint16_class_plane_is_chosen_per_image_and_per_call(capi):
             for i in range(len(batch)):
                 check_detect(capi, eng, batch[i], 60, 10, batch_index=i, res=res)
             used = [eng.debug_used_plane(i) for i in range(len(batch))]
-            ps = (4 if st["max"] < 4096 else 5 if st["max"] < 8192 else 6) if (st["one_pass"] and st["have_pred"]) else 0
-            pa = max(0, st["mean"] - (15 << ps) // 2)
+            pred = st["one_pass"] and st["have_pred"]
+            wide = 4 if st["max"] < 4096 else 5 if st["max"] < 8192 else 6
+            ps = 0 if st["spread"] <= 10 else wide          # thresholds of the last call close together: one value per class
+            pa = max(0, st["mean"] - (7 if ps == 0 else (15 << wide) // 2))
             coulds = []
             for i in range(len(batch)):
                 x = int(info[i]["x_thr"])
-                q = min(max(x - pa, 0) >> ps, 15) if ps else 0
+                q = min(max(x - pa, 0) >> ps, 15)
+                settled = q <= 14 and x == pa + ((q + 1) << ps) - 1      # the class of x_thr ends at x_thr: clear as a whole
                 lo = pa + (q << ps)
-                n_in = int(((batch[i] >= lo) & (batch[i] < lo + (1 << ps))).sum()) if ps else 0
-                coulds.append(bool(ps and 1 <= q <= 14 and n_in * 2048 <= batch[i].size))
-            expect = [bool(ps and st["plane_on"] and c) for c in coulds]
+                n_in = int(((batch[i] >= lo) & (batch[i] < lo + (1 << ps))).sum())
+                coulds.append(bool(pred and (settled or (1 <= q <= 14 and n_in * 2048 <= batch[i].size))))
+            expect = [bool(pred and st["plane_on"] and c) for c in coulds]
             assert used == expect, (used, expect, st, ps, pa)
             seen.update(used)
-            if ps:
+            if pred:
                 st["plane_on"] = 2 * sum(coulds) >= len(batch)
+            thr = [int(info[i]["x_thr"]) for i in range(len(batch))]
             st["max"] = int(batch.max()); st["one_pass"] = st["max"] < 16384
-            st["mean"] = int(sum(int(info[i]["x_thr"]) for i in range(len(batch))) // len(batch)); st["have_pred"] = True
+            st["mean"] = sum(thr) // len(batch); st["spread"] = max(thr) - min(thr); st["have_pred"] = True
             return used
         assert run(sep) == [False, False]           # nothing known: two-pass histogram, no plane
         assert run(sep) == [True, True]             # one pass, classes centred on the first call's thresholds
@@ -347,6 +351,30 @@ def test_uint16_class_plane_is_chosen_per_image_and_per_call(capi):
         for _ in range(3):
             run(mixed)
         assert seen == {True, False}
+    finally:
+        eng.close()
+
+
+def test_uint16_series_with_a_stable_threshold(capi):
+    """Frames of one scene: thresholds within a few values of each other, lying inside the background noise (a crowded
+    class whatever its width).  After one call the classes are one value wide around the mean threshold, the threshold is
+    the last value of its class, and the mask comes from the plane alone -- same results as from the frames."""
+    rng = np.random.default_rng(23)
+    base = _u16_separated(rng, noise=True)
+    series = np.stack([np.ascontiguousarray(np.roll(base, (3 * k, 5 * k), (0, 1))) for k in range(3)])
+    series[1, 0, 0] += 1; series[2, 5, 5] -= 1                      # not quite the same histogram
+    eng = capi.Engine(device=0, max_h=160, max_w=256, max_batch=3)
+    try:
+        used = []
+        for call in range(4):
+            res = eng.detect(series, 60, 10)
+            for i in range(3):
+                check_detect(capi, eng, series[i], 60, 10, batch_index=i, res=res)
+            used.append([eng.debug_used_plane(i) for i in range(3)])
+        thr = [int(res[1][i]["x_thr"]) for i in range(3)]
+        assert max(thr) - min(thr) <= 10
+        assert used[0] == [False] * 3                               # two-pass histogram
+        assert used[-1] == [True] * 3, used
     finally:
         eng.close()
 
