@@ -132,13 +132,22 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
                 eqrows &= eqrows - 1;
                 const uint2 a = *(const uint2*)(bp + (int64_t)r * rowb);
                 const uint8_t* px = base + ((int64_t)(r0 + r) * W + (int64_t)cg * 16) * (MODE == 2 ? 3 : 2);
-                unsigned long long nib = (unsigned long long)a.x | ((unsigned long long)a.y << 32);
-#pragma nounroll
-                for (int k = 0; k < 16; ++k, nib >>= 4) {
-                    if ((uint32_t)(nib & 15ull) != q) continue;
-                    const bool set = (MODE == 2) ? (2125u * px[3 * k] + 7154u * px[3 * k + 1] + 721u * px[3 * k + 2]) >= G_thr
-                                                 : (int)((const uint16_t*)px)[k] > x_thr;
-                    if (set) atomicOr((unsigned long long*)&o[k], 1ull << r);
+                // only the nibbles equal to q are visited: the zero-nibble flags of x ^ q8 (a flag may also come up for a
+                // nibble just above a zero one, hence the exact re-check)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const uint32_t x = d ? a.y : a.x;
+                    const uint32_t v = x ^ q8;
+                    uint32_t z = (v - 0x11111111u) & ~v & 0x88888888u;
+                    while (z) {
+                        const int b = __ffs((int)z) - 1;                  // bit 3 of the nibble
+                        z &= z - 1;
+                        if (((x >> (b - 3)) & 15u) != q) continue;
+                        const int k = d * 8 + (b >> 2);
+                        const bool set = (MODE == 2) ? (2125u * px[3 * k] + 7154u * px[3 * k + 1] + 721u * px[3 * k + 2]) >= G_thr
+                                                     : (int)((const uint16_t*)px)[k] > x_thr;
+                        if (set) atomicOr((unsigned long long*)&o[k], 1ull << r);
+                    }
                 }
             }
             return;
