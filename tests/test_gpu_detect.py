@@ -217,7 +217,8 @@ def test_class_plane_is_chosen_per_image_and_per_call(capi):
 def _u16_frame(rng, top, H=160, W=256):
     g = rng.integers(top // 40, top // 8, size=(H, W)).astype(np.uint16)
     for c0 in (30, 110, 190):
-        g[15:140, c0:c0 + 12] = rng.integers(top // 2, top, size=(125, 12))
+        blk = g[15:140, c0:c0 + 12]
+        blk[...] = rng.integers(top // 2, top, size=blk.shape)
     return g
 
 
@@ -276,7 +277,8 @@ def _u16_separated(rng, H=160, W=256, noise=False):
         g = rng.integers(90, 110, size=(H, W)).astype(np.uint16)
         g[rng.integers(0, H, 12), rng.integers(0, W, 12)] = 150            # the threshold lands here, in a nearly empty range
     for c0 in (30, 110, 190):
-        g[15:140, c0:c0 + 12] = rng.integers(2000, 3000, size=(125, 12))
+        blk = g[15:140, c0:c0 + 12]                                            # (smaller frames: what fits)
+        blk[...] = rng.integers(2000, 3000, size=blk.shape)
     return g
 
 
@@ -351,6 +353,27 @@ def test_uint16_class_plane_is_chosen_per_image_and_per_call(capi):
         for _ in range(3):
             run(mixed)
         assert seen == {True, False}
+    finally:
+        eng.close()
+
+
+def test_one_handle_across_shapes_and_dtypes(capi):
+    """What a handle learnt from one kind of input (one-pass histogram, class-plane centre, window length) must not leak
+    into the next: frames of other sizes, colour images and 8-bit 2-D images in between, bigger batches after smaller."""
+    rng = np.random.default_rng(24)
+    eng = capi.Engine(device=0, max_h=192, max_w=256, max_c=3, max_batch=3)
+    try:
+        a = np.stack([_u16_separated(rng) for _ in range(2)])                       # 160 x 256
+        b = np.stack([_u16_separated(rng, H=96, W=128, noise=True) for _ in range(3)])
+        c = np.stack([_u16_frame(rng, 60000, H=192, W=240)])                        # high values: back to two passes; W % 16 == 0
+        rgb = rng.integers(0, 256, size=(2, 64, 64, 3), dtype=np.uint8)
+        rgb[:, 10:50, 20:28] = 250
+        g8 = rng.integers(0, 100, size=(1, 100, 90), dtype=np.uint8)
+        g8[:, 20:80, 30:36] = 220
+        for batch in (a, a, b, rgb, a, b, b, g8, c, c, a, a, a, b):
+            res = eng.detect(batch, 40, 6)
+            for i in range(len(batch)):
+                check_detect(capi, eng, batch[i], 40, 6, batch_index=i, res=res)
     finally:
         eng.close()
 
