@@ -156,6 +156,27 @@ def test_analyze_window_length_hint_and_its_fallback():
         eng.close()
 
 
+def test_analyze_uint16_frames_on_a_settled_handle():
+    """detect + profile + peaks on 16-bit frames, the same handle four times: two-pass histogram first, then the one-pass
+    form with the class plane (synthetic frames: thresholds in a sparse part of the histogram) -- strips, profiles and
+    peaks stay the oracle's; the plane is used once the handle has settled."""
+    import image_analysis_amd._capi as capi
+    from image_analysis_amd.synth import synth_u16
+    imgs = np.stack([synth_u16(512, 512, 10, 90 + i) for i in range(3)])
+    eng = capi.Engine(device=0, max_h=512, max_w=512, max_batch=3)
+    try:
+        used = []
+        for _ in range(4):
+            n, _info = _check_analyze(eng, imgs, 240, 12)
+            assert n >= 3
+            used.append([eng.debug_used_plane(i) for i in range(3)])
+        assert used[0] == [False] * 3
+        assert eng.debug_one_pass()
+        assert any(used[-1]), used
+    finally:
+        eng.close()
+
+
 def test_analyze_with_the_largest_strip_list():
     """max_strips = 1024 is the API's upper limit: k_finalize's accepted / kept lists (dynamic LDS) are then at their largest."""
     import image_analysis_amd._capi as capi
