@@ -242,8 +242,11 @@ LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool 
     // one call site for both sides (the function is inlined on the device: every call site is a full copy)
     Peak b = analyze_peaks_at_t(take_left ? p : right, take_left ? left_len : right_len, take_left ? il : ir, inverse, window, walk, sum);
     if (!take_left) {
-        b.start += e + rng;
-        b.end += e + rng;
+        // image_analysis adds `end_index + range` (detection.py:238-239, also after its [end_index + 1:] fallback slice);
+        // inverse_image_analysis slices with `range` (:260-261) but adds the literal `end_index + 1` (:274-275)
+        const int off = fallback ? e + rng : e + 1;
+        b.start += off;
+        b.end += off;
     }
     const int s2 = b.start, e2 = b.end;
     if ((s2 <= s && e2 > s) || (s2 <= e && e2 > e) || (s2 >= s && e2 <= e)) return out;

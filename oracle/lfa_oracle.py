@@ -285,8 +285,9 @@ def _two_peaks(profile, inverse: bool, rng: int, fallback: bool):
     side = left if take_left else right
     s2, e2, a2 = analyze_peaks(side, inverse=inverse)
     if not take_left:
-        s2 += e + rng
-        e2 += e + rng
+        off = e + rng if fallback else e + 1          # detection.py:238-239 adds `range`, :274-275 the literal 1
+        s2 += off
+        e2 += off
     if (s2 <= s and e2 > s) or (s2 <= e and e2 > e) or (s2 >= s and e2 <= e):
         return first
     return first + [(s2, e2, a2)]

@@ -11,6 +11,17 @@ What it produces (all of it data: inputs + expected outputs, no reference source
                                         (detection.py:205-316: image_analysis, inverse_image_analysis,
                                         analyze_peaks) EXECUTED here from the reference's file.
 * ref_region_lists.npz                  inputs + outputs of detection.py:118-153 (check_duplicate, remove_outliers).
+* ref_skimage_detect.npz                the whole of detect_lateral_flow_tests (detection.py:31-153) EXECUTED here over the
+                                        reference's vendored scikit-image 0.20.0 Python sources (vendored_skimage.py: rgb2gray,
+                                        adjust_gamma, threshold_otsu + exposure.histogram, binary_erosion / dilation, label,
+                                        regionprops), on small colour / uint8 / uint16 inputs and edge cases: inputs, the
+                                        threshold's bits, SHA-256 of gray / gamma / mask / opened mask / label image, K, the
+                                        bbox + area table, the returned crops' boxes.  `--only-skimage` writes this and the next.
+* ref_skimage_vectors.npz               expected values the vendored skimage's OWN test-suite holds for the functions on the
+                                        path (gamma 0.5 / 2.0 tables of exposure/tests/test_exposure.py:622-686, the Otsu image
+                                        of filters/tests/test_thresholding.py:33-61, :307-314), read out of those files as data;
+                                        plus outputs of the vendored gaussian / rescale_intensity / invert / adjust_gamma chain
+                                        (analyze_plot's point operations, detection.py:535-539) and of gaussian (:166).
 * image1_decoded.npz                    images/image1.jpg decoded with PIL (cv2 is absent here; the decoded
                                         array is stored because decoders may differ by an LSB).
 * real_samples.npz                      seven more of the reference's sample inputs (images/), decoded with PIL: three
@@ -80,6 +91,17 @@ def synth_strip(rng, h, w, c, dtype, n_bands):
     return np.clip(base, 0, np.iinfo(dtype).max).astype(dtype)
 
 
+def two_band_strip(rng, h, w, c, dtype, order, sign):
+    """Two transverse bands at the given height fractions: the first of `order` strong, the second weaker."""
+    hi = 200 if dtype == np.uint8 else 3000
+    base = rng.normal(hi * 0.6, hi * 0.01, size=(h, w) + ((c,) if c else ()))
+    rows = np.arange(h)[:, None]
+    for pos, depth in zip(order, (0.3, 0.15)):
+        prof = sign * depth * hi * np.exp(-0.5 * ((rows - pos * h) / 5.0) ** 2)
+        base += prof if not c else prof[:, :, None]
+    return np.clip(base, 0, np.iinfo(dtype).max).astype(dtype)
+
+
 def main():
     warnings.simplefilter("ignore")
     ns = load_reference_functions()
@@ -99,6 +121,9 @@ def main():
     assert np.array_equal(prof, colB)
 
     # ---- image_analysis / inverse_image_analysis on synthetic strips ---------------------------
+    # `range` takes 1, 3 and 15 for BOTH functions: image_analysis adds `end_index + range` to a right-hand second
+    # peak (detection.py:238-239) while inverse_image_analysis slices with `range` (:260-261) and adds the literal
+    # `end_index + 1` (:274-275); only range != 1 on the inverse function tells the two apart.
     out = {}
     k = 0
     cases = []
@@ -106,27 +131,46 @@ def main():
         for c in (0, 3):
             for (h, w) in ((1020, 51), (400, 40), (64, 17), (37, 9), (12, 5)):
                 for selected in (False, True):
-                    cases.append((dtype, c, h, w, selected, int(rng.integers(1, 4))))
-    for dtype, c, h, w, selected, nb in cases:
-        reg = synth_strip(rng, h, w, c, dtype, nb)
+                    cases.append((dtype, c, h, w, selected, int(rng.integers(1, 4)), None))
+    # two bands of known order: the stronger one first, a weaker one well to its right (and mirrored), so that the
+    # second peak is taken from the right-hand (resp. left-hand) remainder for every `range`
+    for dtype in (np.uint8, np.uint16):
+        for c in (0, 3):
+            for (h, w) in ((1020, 51), (600, 30)):
+                for order in ((0.33, 0.52), (0.52, 0.33)):
+                    for sign in (-1, 1):
+                        cases.append((dtype, c, h, w, False, 2, (order, sign)))
+    right_inverse_wide = 0
+    for rid, (dtype, c, h, w, selected, nb, two) in enumerate(cases):
+        if two is None:
+            reg = synth_strip(rng, h, w, c, dtype, nb)
+        else:
+            reg = two_band_strip(rng, h, w, c, dtype, *two)
+        out[f"r{rid}"] = reg                               # every region once; its cases name it (c<k>_rid)
         for inverse in (False, True):
             if inverse and not c:
                 continue                                   # detection.py:249 needs three dimensions
             fn = inverse_image_analysis if inverse else image_analysis
-            try:
-                prof, peaks = fn(reg, selected)
-            except ValueError:
-                continue                                   # empty profile (argmax of empty) -- tested separately
-            n, idx, area = pack_peaks(peaks)
-            out[f"c{k}_region"] = reg
-            out[f"c{k}_selected"] = np.array(selected)
-            out[f"c{k}_inverse"] = np.array(inverse)
-            out[f"c{k}_profile"] = prof
-            out[f"c{k}_n"] = np.array(n)
-            out[f"c{k}_idx"] = idx
-            out[f"c{k}_area"] = area
-            k += 1
+            for rg in (None, 1, 3, 15):                    # None: the function's own default
+                try:
+                    prof, peaks = fn(reg, selected) if rg is None else fn(reg, selected, rg)
+                except ValueError:
+                    continue                               # empty profile (argmax of empty) -- tested separately
+                n, idx, area = pack_peaks(peaks)
+                eff = (1 if inverse else 15) if rg is None else rg
+                if inverse and eff != 1 and n == 2 and idx[1][0] > idx[0][1]:
+                    right_inverse_wide += 1
+                out[f"c{k}_rid"] = np.array(rid)
+                out[f"c{k}_selected"] = np.array(selected)
+                out[f"c{k}_inverse"] = np.array(inverse)
+                out[f"c{k}_range"] = np.array(eff)
+                out[f"c{k}_profile"] = prof
+                out[f"c{k}_n"] = np.array(n)
+                out[f"c{k}_idx"] = idx
+                out[f"c{k}_area"] = area
+                k += 1
     out["n_cases"] = np.array(k)
+    assert right_inverse_wide >= 8, right_inverse_wide     # the cases that separate `+ range` from `+ 1`
 
     # ---- analyze_peaks on raw float profiles (plateaus, ties, monotone, tiny) ------------------
     profs = []
@@ -185,6 +229,7 @@ def main():
     im = np.array(Image.open(os.path.join(REF, "images", "image1.jpg")))
     np.savez_compressed(os.path.join(HERE, "image1_decoded.npz"), gray=im)
     write_real_samples()
+    write_skimage_fixtures()
     print("golden fixtures written:", sorted(os.listdir(HERE)))
 
 
@@ -206,7 +251,157 @@ def write_real_samples():
     np.savez_compressed(os.path.join(HERE, "real_samples.npz"), **out)
 
 
+def sha(a):
+    import hashlib
+    a = np.ascontiguousarray(a)
+    return np.frombuffer(hashlib.sha256(a.tobytes()).digest(), dtype=np.uint8).copy()
+
+
+def crop_box(image, crop):
+    """[minr, maxr, minc, maxc] of a view of `image` (as numpy clipped it)."""
+    off = crop.__array_interface__["data"][0] - image.__array_interface__["data"][0]
+    r, rem = divmod(off, image.strides[0])
+    c = rem // image.strides[1]
+    return [int(r), int(r + crop.shape[0]), int(c), int(c + crop.shape[1])]
+
+
+def skimage_detect_cases():
+    """(name, image, min_maxr, min_maxc, line_length) -- small inputs over every branch of the detect path."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from image_analysis_amd.synth import synth_rgb, synth_u16
+    rng = np.random.default_rng(77)
+    gui = lambda im: (int(int(im.shape[1] / 40) * 20), int(im.shape[1] / 40))          # detection.py:457-460
+    cases = []
+    for seed, (H, W) in ((11, (256, 192)), (12, (256, 192)), (13, (192, 256)), (3, (320, 384))):
+        im = synth_rgb(H, W, 6 if W < 300 else 8, seed)
+        cases.append((f"synth_rgb_{H}x{W}_s{seed}", im, *gui(im), 10))
+    im = synth_rgb(203, 171, 5, 21)                                                   # ragged sides (scalar kernels)
+    cases.append(("synth_rgb_ragged", im, *gui(im), 10))
+    g1 = np.load(os.path.join(HERE, "image1_decoded.npz"))["gray"]
+    cases.append(("image1_gray", g1, *gui(g1), 10))
+    cases.append(("image1_bgr", np.ascontiguousarray(np.repeat(g1[:, :, None], 3, axis=2)), *gui(g1), 10))
+    rs = np.load(os.path.join(HERE, "real_samples.npz"))
+    for key in ("image2", "image4", "image7"):
+        cases.append((key + "_bgr", np.ascontiguousarray(np.repeat(rs[key][:, :, None], 3, axis=2)), *gui(rs[key]), 10))
+    cases.append(("test_strip_buggy_bgr", rs["test_strip_buggy_bgr"], *gui(rs["test_strip_buggy_bgr"]), 10))
+    a = np.ascontiguousarray(rs["austin_u16_crop"][:384, :512])
+    cases.append(("austin_u16_384x512", a, *gui(a), 10))
+    fr = np.array(Image.open(os.path.join(HERE, "excel2_frame.png")))               # threshold inside the noise: many labels
+    cases.append(("excel2_u16_512", np.ascontiguousarray(fr[300:812, 700:1212]), *gui(fr[300:812, 700:1212]), 10))
+    wk = np.ascontiguousarray(rs["wick_crop"][200:584, 256:768])
+    cases.append(("wick_bgr_384x512", np.ascontiguousarray(np.repeat(wk[:, :, None], 3, axis=2)), *gui(wk), 10))
+    u = synth_u16(256, 256, 6, 5)
+    cases.append(("synth_u16_256", u, *gui(u), 10))
+    cases.append(("synth_u16_256_L5", u, 40, 4, 5))
+    cases.append(("constant_u8", np.full((64, 48), 7, np.uint8), 20, 3, 10))
+    cases.append(("constant_rgb", np.full((64, 48, 3), 9, np.uint8), 20, 3, 10))
+    cases.append(("constant_u16", np.full((40, 40), 1234, np.uint16), 20, 3, 10))
+    # strips touching all four borders, a foreground corner (labeled[0,0] != 0), overlapping expanded boxes, boxes that
+    # reach beyond the image, vertical runs of 9 / 10 / 11 pixels, one wide outlier
+    e = (rng.integers(20, 40, size=(160, 200))).astype(np.uint8)
+    bright = lambda r0, r1, c0, c1: e.__setitem__((slice(r0, r1), slice(c0, c1)), rng.integers(200, 240, size=(r1 - r0, c1 - c0)))
+    bright(0, 120, 0, 12); bright(30, 160, 30, 42); bright(10, 140, 44, 56); bright(5, 150, 188, 200)
+    bright(20, 29, 70, 90); bright(40, 50, 70, 90); bright(60, 71, 70, 90); bright(90, 150, 100, 170)
+    bright(0, 4, 120, 140); bright(156, 160, 120, 140)
+    cases.append(("edges_u8", e.copy(), 100, 5, 10))
+    cases.append(("edges_u8_mm0", e.copy(), 0, 0, 10))
+    cases.append(("edges_rgb", np.ascontiguousarray(np.stack([e, np.clip(e.astype(int) + 2, 0, 255).astype(np.uint8), e], axis=2)), 100, 5, 10))
+    cases.append(("edges_u16", (e.astype(np.uint16) * 13), 100, 5, 10))
+    cases.append(("edges_u8_L3", e.copy(), 30, 5, 3))
+    return cases
+
+
+def write_skimage_fixtures():
+    import vendored_skimage as V
+    warnings.simplefilter("ignore")
+    out = {}
+    names = []
+    for name, im, mm_r, mm_c, L in skimage_detect_cases():
+        fn, ns = V.reference_detect(mm_r, mm_c)
+        crops = fn(im, L)
+        t = ns["trace"]
+        names.append(name)
+        out[f"{name}__image"] = im
+        out[f"{name}__params"] = np.array([mm_r, mm_c, L], dtype=np.int64)
+        out[f"{name}__threshold"] = np.asarray(t["threshold"])               # int for integer images, float64 for colour
+        if im.ndim == 3:
+            out[f"{name}__gray_sha"] = sha(t["gray"])
+        out[f"{name}__gamma_sha"] = sha(t["gamma"])
+        out[f"{name}__mask_sha"] = sha(np.asarray(t["gamma"] > t["threshold"], dtype=np.uint8))
+        out[f"{name}__opened_sha"] = sha(np.asarray(t["dilated"], dtype=np.uint8))
+        labels = np.asarray(t["labels"])
+        out[f"{name}__labels_sha"] = sha(labels.astype(np.int32))
+        out[f"{name}__n_labels"] = np.array(int(labels.max()), dtype=np.int64)
+        out[f"{name}__label00"] = np.array(int(labels[0, 0]), dtype=np.int64)
+        out[f"{name}__table"] = np.array([[*r.bbox, int(r.area)] for r in t["regions"]], dtype=np.int64).reshape(-1, 5)
+        out[f"{name}__boxes"] = np.array([crop_box(im, c) for c in crops], dtype=np.int64).reshape(-1, 4)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "ref_skimage_detect.npz"), **out)
+
+    # ---- the excel2 frame (stored as png already): the reference's own detect on its own frame -------------------------
+    frame = np.array(Image.open(os.path.join(HERE, "excel2_frame.png")))
+    fn, ns = V.reference_detect(1020, 51)
+    crops = fn(frame)
+    t = ns["trace"]
+    vec = {"excel2_threshold": np.asarray(t["threshold"]), "excel2_n_labels": np.array(int(np.asarray(t["labels"]).max())),
+           "excel2_boxes": np.array([crop_box(frame, c) for c in crops], dtype=np.int64),
+           "excel2_mask_sha": sha(np.asarray(t["gamma"] > t["threshold"], dtype=np.uint8)),
+           "excel2_labels_sha": sha(np.asarray(t["labels"]).astype(np.int32))}
+
+    # ---- expected values held by the vendored skimage's own tests, read out as data -------------------------------------
+    import ast
+    sp = os.path.join(V.SP, "skimage")
+
+    def literal_arrays(path, func):
+        tree = ast.parse(open(path).read())
+        found = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.FunctionDef) and node.name == func:
+                for sub in ast.walk(node):
+                    if isinstance(sub, ast.Call) and getattr(sub.func, "attr", "") == "array" and sub.args and isinstance(sub.args[0], ast.List):
+                        found.append(np.array(ast.literal_eval(sub.args[0])))
+        return found
+    te = os.path.join(sp, "exposure", "tests", "test_exposure.py")
+    vec["gamma_half_table"] = literal_arrays(te, "test_adjust_gamma_less_one")[0].astype(np.uint8)        # :626-653
+    vec["gamma_two_table"] = literal_arrays(te, "test_adjust_gamma_greater_one")[0].astype(np.uint8)     # :664-683
+    tt = os.path.join(sp, "filters", "tests", "test_thresholding.py")
+    vec["otsu_simple_image"] = literal_arrays(tt, "setup_method")[0].astype(np.int64)                    # :34-38; == 2, -2: == 0, float: [2,3)
+    assert vec["gamma_half_table"].size == 256 and vec["gamma_two_table"].size == 256 and vec["otsu_simple_image"].shape == (5, 5)
+
+    # ---- analyze_plot point operations and gaussian through the vendored sources ----------------------------------------
+    sk = V.skimage()
+    rng = np.random.default_rng(5)
+    k = 0
+    for dt in (np.uint8, np.uint16):
+        top = np.iinfo(dt).max
+        allv = np.arange(top + 1, dtype=dt).reshape(-1, 256)          # 2-D: every value of the dtype once
+        for gamma_level, lo, hi, inv in ((1, None, None, False), (0.5, None, None, False), (2, None, None, True),
+                                         (1, 0.1 * top, 0.8 * top, False), (0.7, 10, top / 3, True), (1.5, 5, 5, False)):
+            r = sk.exposure.adjust_gamma(allv, gamma_level)
+            if lo is not None or hi is not None:
+                r = sk.exposure.rescale_intensity(r, in_range=(lo, hi))
+            if inv:
+                r = sk.util.invert(r)
+            vec[f"pointop{k}_params"] = np.array([gamma_level, -1 if lo is None else lo, -1 if hi is None else hi, inv], dtype=np.float64)
+            vec[f"pointop{k}_dtype"] = np.array(np.dtype(dt).itemsize)
+            vec[f"pointop{k}_table"] = np.asarray(r).reshape(-1)
+            assert np.asarray(r).dtype == dt
+            k += 1
+    vec["n_pointops"] = np.array(k)
+    g = 0
+    for im in (rng.integers(0, 256, size=(37, 53), dtype=np.uint8), rng.integers(0, 256, size=(24, 31, 3), dtype=np.uint8),
+               rng.integers(0, 4096, size=(33, 40), dtype=np.uint16)):
+        vec[f"gauss{g}_image"] = im
+        vec[f"gauss{g}_out"] = sk.filters.gaussian(im, sigma=1)                   # detection.py:166
+        g += 1
+    vec["n_gauss"] = np.array(g)
+    np.savez_compressed(os.path.join(HERE, "ref_skimage_vectors.npz"), **vec)
+    print("skimage fixtures:", len(names), "detect cases;", k, "point-op tables;", g, "gaussian images")
+
+
 if __name__ == "__main__":
     if "--only-samples" in sys.argv:
         sys.exit(write_real_samples())
+    if "--only-skimage" in sys.argv:
+        sys.exit(write_skimage_fixtures())
     sys.exit(main())

@@ -129,7 +129,7 @@ def test_device_peak_code_matches_reference_vectors(hc, golden_dir):
         prof = np.ascontiguousarray(g[f"c{k}_profile"])
         inv = int(g[f"c{k}_inverse"])
         st, en, ar = (C.c_int * 2)(), (C.c_int * 2)(), (C.c_double * 2)()
-        n = hc.hc_two_peaks(prof.ctypes.data_as(dp), len(prof), inv, 1 if inv else 15, 0 if inv else 1, 25, st, en, ar)
+        n = hc.hc_two_peaks(prof.ctypes.data_as(dp), len(prof), inv, int(g[f"c{k}_range"]), 0 if inv else 1, 25, st, en, ar)
         assert n == int(g[f"c{k}_n"])
         for q in range(n):
             assert (st[q], en[q]) == tuple(int(v) for v in g[f"c{k}_idx"][q]) and ar[q] == g[f"c{k}_area"][q]

@@ -36,11 +36,11 @@ def test_image_analysis_reference_vectors(det, golden_dir):
     n = int(g["n_cases"])
     exact_area = 0
     for k in range(n):
-        reg = g[f"c{k}_region"]
+        reg = g[f"r{int(g[f'c{k}_rid'])}"]
         sel = bool(g[f"c{k}_selected"])
         inv = bool(g[f"c{k}_inverse"])
         fn = det.inverse_image_analysis if inv else det.image_analysis
-        prof, peaks = fn(reg, sel)
+        prof, peaks = fn(reg, sel, int(g[f"c{k}_range"]))
         assert np.array_equal(prof, g[f"c{k}_profile"]), k
         assert len(peaks) == int(g[f"c{k}_n"]), k
         for i, (s, e, a) in enumerate(peaks):

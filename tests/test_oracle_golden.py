@@ -59,13 +59,14 @@ def test_excel2_profile_and_peaks(excel2):
 def test_image_analysis_matches_reference_vectors(golden_dir):
     g = np.load(os.path.join(golden_dir, "ref_profile_peaks.npz"))
     n_cases = int(g["n_cases"])
-    assert n_cases > 50
+    assert n_cases > 200
+    assert {int(g[f'c{k}_range']) for k in range(n_cases) if bool(g[f'c{k}_inverse'])} == {1, 3, 15}
     for k in range(n_cases):
-        reg = g[f"c{k}_region"]
+        reg = g[f"r{int(g[f'c{k}_rid'])}"]
         sel = bool(g[f"c{k}_selected"])
         inv = bool(g[f"c{k}_inverse"])
         fn = O.inverse_image_analysis if inv else O.image_analysis
-        prof, peaks = fn(reg, sel)
+        prof, peaks = fn(reg, sel, int(g[f"c{k}_range"]))
         assert np.array_equal(prof, g[f"c{k}_profile"]), k
         assert len(peaks) == int(g[f"c{k}_n"]), k
         for i, (s, e, a) in enumerate(peaks):
