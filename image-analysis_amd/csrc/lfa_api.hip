@@ -87,13 +87,26 @@ struct EventTimer : lfa::KernelTimer {
 
 thread_local lfa::KernelTimer* lfa::g_timer = nullptr;
 
+// Per-call device workspace of the detect path.  A handle owns one in hipMalloc memory (grown by ensure_workspace);
+struct Workspace {
+    Buf info, hist, otsu_w, otsu_s, edges, edges_i, bins, maskT, col_cnt, run_tmp, run_se, run_col, parent, area, bbox, rowcnt, rowpos, rootlist, bucket, label_of_run, root_of_label, cand,
+        cand_sum, cand_rs_off, rowsum, slot_rs_off, rois;
+    std::vector<Buf*> all() {
+        return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_tmp, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
+                &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &rois};
+    }
+};
+
 struct LfaContext {
     int device = 0;
     int max_h = 0, max_w = 0, max_c = 0, max_batch = 0;
     int gray_variant = LFA_GRAY_FMA_102;
     int debug_flags = 0;
-    Buf info, hist, otsu_w, otsu_s, edges, edges_i, bins, maskT, col_cnt, run_tmp, run_se, run_col, parent, area, bbox, rowcnt, rowpos, rootlist, bucket, label_of_run, root_of_label, cand,
-        cand_sum, cand_rs_off, rowsum, slot_rs_off, lut8, lut16, rois;
+    Workspace ws;
+    Buf lut8, lut16;
+    hipEvent_t done_event = nullptr;       // end of the handle's most recent detect/analyze call (orders calls across streams)
+    hipStream_t last_stream = nullptr;
+    bool have_done = false;
     lfa::Job last{};
     bool have_last = false;
     EventTimer* timer = nullptr;
@@ -117,8 +130,9 @@ struct LfaContext {
     int u16_thr_mean = 0, u16_thr_spread = 0;   // mean and (largest - smallest) threshold of that call
     int win_hint = 0;                      // longest analysis window of the last completed call (rows), 0 = unknown
     std::vector<Buf*> all() {
-        return {&info, &hist, &otsu_w, &otsu_s, &edges, &edges_i, &bins, &maskT, &col_cnt, &run_tmp, &run_se, &run_col, &parent, &area, &bbox, &rowcnt, &rowpos, &rootlist, &bucket, &label_of_run,
-                &root_of_label, &cand, &cand_sum, &cand_rs_off, &rowsum, &slot_rs_off, &lut8, &lut16, &rois, &plane_stats};
+        std::vector<Buf*> v = ws.all();
+        v.push_back(&lut8); v.push_back(&lut16); v.push_back(&plane_stats);
+        return v;
     }
 };
 
@@ -147,45 +161,62 @@ int run_capacity(int H, int W, int L) {
     return (int)cap;
 }
 
-// size every buffer for (n images of H x W, line_length L, dtype); grows only
-int ensure_workspace(LfaContext* h, int n, int H, int W, int C, int dtype, int L, int max_strips) {
+// Every workspace buffer of one call (n images of H x W x C of `dtype`, line_length L, max_strips) with its size in bytes.
+// plane: with the 4-bit class plane; the float32 Otsu buffers only for 2-D images above 2^24 pixels (k_otsu_int).
+struct WsNeeds {
+    struct Item { Buf* b; size_t bytes; };
+    Item item[32];
+    int n = 0;
+    void add(Buf& b, size_t bytes) { item[n].b = &b; item[n].bytes = bytes; ++n; }
+};
+
+WsNeeds workspace_needs(Workspace& w, int n, int H, int W, int C, int dtype, int L, int max_strips, bool plane) {
     const size_t N = (size_t)n;
     const int HB = (H + 63) / 64;
     const size_t cap = (size_t)run_capacity(H, W, L);
     const size_t hist_stride = (dtype == LFA_U16) ? lfa::kHistBinsU16 : 256;
-    int rc;
-    if ((rc = ensure(h->info, N * sizeof(LfaImageInfo)))) return rc;
-    if ((rc = ensure(h->hist, N * hist_stride * 4))) return rc;
+    WsNeeds q;
+    q.add(w.info, N * sizeof(LfaImageInfo));
+    q.add(w.hist, N * hist_stride * 4);
     if (C == 1 && (size_t)H * W > ((size_t)1 << 24)) {          // float32-rounded Otsu weights (k_otsu_int)
-        if ((rc = ensure(h->otsu_w, N * 2 * hist_stride * 4))) return rc;
-        if ((rc = ensure(h->otsu_s, N * 2 * hist_stride * 8))) return rc;
+        q.add(w.otsu_w, N * 2 * hist_stride * 4);
+        q.add(w.otsu_s, N * 2 * hist_stride * 8);
     }
-    if ((rc = ensure(h->edges, N * lfa::kEdges * 8))) return rc;
-    if ((rc = ensure(h->edges_i, N * lfa::kEdgesI * 4))) return rc;
-    // class plane: colour images; uint16 frames once the handle takes the one-pass histogram (make_job)
-    const bool u16_plane_possible = dtype == LFA_U16 && C == 1 && !(h->debug_flags & 8) && (h->u16_one_pass || (h->debug_flags & 16));
-    if ((C == 3 || u16_plane_possible) && (rc = ensure(h->bins, N * (((size_t)H * W + 1) / 2)))) return rc;
-    if ((rc = ensure(h->maskT, N * HB * W * 8))) return rc;
-    if ((rc = ensure(h->col_cnt, N * (W + 1) * 4))) return rc;
-    if ((rc = ensure(h->run_tmp, N * cap * 4))) return rc;
-    if ((rc = ensure(h->run_se, N * cap * 4))) return rc;
-    if ((rc = ensure(h->run_col, N * cap * 2))) return rc;
-    if ((rc = ensure(h->parent, N * cap * 4))) return rc;
-    if ((rc = ensure(h->area, N * cap * 4))) return rc;
-    if ((rc = ensure(h->bbox, N * cap * 16))) return rc;
-    if ((rc = ensure(h->rowcnt, N * ((size_t)H + 1) * 4))) return rc;
-    if ((rc = ensure(h->rowpos, N * ((size_t)H + 1) * 4))) return rc;
-    if ((rc = ensure(h->rootlist, N * cap * 4))) return rc;
-    if ((rc = ensure(h->bucket, N * cap * 4))) return rc;
-    if ((rc = ensure(h->label_of_run, N * cap * 4))) return rc;
-    if ((rc = ensure(h->root_of_label, N * cap * 4))) return rc;
+    q.add(w.edges, N * lfa::kEdges * 8);
+    q.add(w.edges_i, N * lfa::kEdgesI * 4);
+    if (plane) q.add(w.bins, N * (((size_t)H * W + 1) / 2));
+    q.add(w.maskT, N * HB * W * 8);
+    q.add(w.col_cnt, N * (W + 1) * 4);
+    q.add(w.run_tmp, N * cap * 4);
+    q.add(w.run_se, N * cap * 4);
+    q.add(w.run_col, N * cap * 2);
+    q.add(w.parent, N * cap * 4);
+    q.add(w.area, N * cap * 4);
+    q.add(w.bbox, N * cap * 16);
+    q.add(w.rowcnt, N * ((size_t)H + 1) * 4);
+    q.add(w.rowpos, N * ((size_t)H + 1) * 4);
+    q.add(w.rootlist, N * cap * 4);
+    q.add(w.bucket, N * cap * 4);
+    q.add(w.label_of_run, N * cap * 4);
+    q.add(w.root_of_label, N * cap * 4);
     const size_t ccap = (size_t)H * W / lfa::kAreaMin + 1;
-    if ((rc = ensure(h->cand, N * ccap * 4))) return rc;
-    if ((rc = ensure(h->cand_sum, N * ccap * 3 * 8))) return rc;
-    if ((rc = ensure(h->cand_rs_off, N * ccap * 4))) return rc;
-    if ((rc = ensure(h->rowsum, N * (size_t)16 * H * 4))) return rc;
-    if ((rc = ensure(h->slot_rs_off, N * (size_t)max_strips * 4))) return rc;
-    if ((rc = ensure(h->rois, N * (size_t)max_strips * sizeof(LfaRoi)))) return rc;
+    q.add(w.cand, N * ccap * 4);
+    q.add(w.cand_sum, N * ccap * 3 * 8);
+    q.add(w.cand_rs_off, N * ccap * 4);
+    q.add(w.rowsum, N * (size_t)16 * H * 4);
+    q.add(w.slot_rs_off, N * (size_t)max_strips * 4);
+    q.add(w.rois, N * (size_t)max_strips * sizeof(LfaRoi));
+    return q;
+}
+
+// the handle's own workspace: hipMalloc memory, grows only (a growing buffer is freed and allocated again -- hipFree waits
+// for the device; lfa_create and lfa_reserve size everything up front so that calls within those limits never get here)
+int ensure_workspace(LfaContext* h, int n, int H, int W, int C, int dtype, int L, int max_strips) {
+    WsNeeds q = workspace_needs(h->ws, n, H, W, C, dtype, L, max_strips, /*plane=*/true);
+    for (int k = 0; k < q.n; ++k) {
+        int rc = ensure(*q.item[k].b, q.item[k].bytes);
+        if (rc) return rc;
+    }
     return LFA_OK;
 }
 
@@ -200,7 +231,7 @@ int check_images(LfaContext* h, const void* images, int dtype, int n, int H, int
     return LFA_OK;
 }
 
-lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
+lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
                   int L, int max_strips) {
     lfa::Job j{};
     j.images = (const uint8_t*)images;
@@ -213,13 +244,13 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
     j.HB = (H + 63) / 64;
     j.run_cap = run_capacity(H, W, L);
     j.max_strips = max_strips;
-    j.info = (LfaImageInfo*)h->info.p;
-    j.hist = (uint32_t*)h->hist.p;
+    j.info = (LfaImageInfo*)w.info.p;
+    j.hist = (uint32_t*)w.hist.p;
     j.hist_stride = (dtype == LFA_U16) ? lfa::kHistBinsU16 : 256;
-    j.otsu_w = (float*)h->otsu_w.p;
-    j.otsu_s = (double*)h->otsu_s.p;
-    j.edges_g = (double*)h->edges.p;
-    j.edges_i = (uint32_t*)h->edges_i.p;
+    j.otsu_w = (float*)w.otsu_w.p;
+    j.otsu_s = (double*)w.otsu_s.p;
+    j.edges_g = (double*)w.edges.p;
+    j.edges_i = (uint32_t*)w.edges_i.p;
     // class plane: colour images on the vector paths only (16-pixel groups in k_hist_rgb, 16-column groups in k_mask)
     j.passes_event = h->passes_event;
     j.plane_stats = (uint32_t*)h->plane_stats.p;
@@ -238,32 +269,32 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
             j.u16_pa = h->u16_thr_mean - (j.u16_ps ? (15 << ps) / 2 : 7);
             if (j.u16_pa < 0) j.u16_pa = 0;
         } else if (h->debug_flags & 4) { j.u16_pred = 1; j.u16_ps = ps; j.u16_pa = 0; }
-        j.u16_plane = (j.u16_pred && h->bins.bytes >= (size_t)n * (((size_t)H * W + 1) / 2) && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->u16_plane_on || (h->debug_flags & 4))) ? 1 : 0;
+        j.u16_plane = (j.u16_pred && w.bins.bytes >= (size_t)n * (((size_t)H * W + 1) / 2) && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->u16_plane_on || (h->debug_flags & 4))) ? 1 : 0;
     }
     const bool rgb_plane = C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4));
-    j.bins = (j.u16_plane || rgb_plane) ? (uint8_t*)h->bins.p : nullptr;
-    j.maskT = (uint64_t*)h->maskT.p;
-    j.col_cnt = (uint32_t*)h->col_cnt.p;
-    j.run_tmp = (uint32_t*)h->run_tmp.p;
+    j.bins = (j.u16_plane || rgb_plane) ? (uint8_t*)w.bins.p : nullptr;
+    j.maskT = (uint64_t*)w.maskT.p;
+    j.col_cnt = (uint32_t*)w.col_cnt.p;
+    j.run_tmp = (uint32_t*)w.run_tmp.p;
     j.runs_per_col = j.run_cap / W;
-    j.run_se = (uint32_t*)h->run_se.p;
-    j.run_col = (uint16_t*)h->run_col.p;
-    j.parent = (int32_t*)h->parent.p;
-    j.area = (int32_t*)h->area.p;
-    j.bbox = (int32_t*)h->bbox.p;
-    j.rowcnt = (uint32_t*)h->rowcnt.p;
-    j.rowpos = (uint32_t*)h->rowpos.p;
-    j.rootlist = (int32_t*)h->rootlist.p;
-    j.bucket = (int32_t*)h->bucket.p;
-    j.label_of_run = (int32_t*)h->label_of_run.p;
-    j.root_of_label = (int32_t*)h->root_of_label.p;
+    j.run_se = (uint32_t*)w.run_se.p;
+    j.run_col = (uint16_t*)w.run_col.p;
+    j.parent = (int32_t*)w.parent.p;
+    j.area = (int32_t*)w.area.p;
+    j.bbox = (int32_t*)w.bbox.p;
+    j.rowcnt = (uint32_t*)w.rowcnt.p;
+    j.rowpos = (uint32_t*)w.rowpos.p;
+    j.rootlist = (int32_t*)w.rootlist.p;
+    j.bucket = (int32_t*)w.bucket.p;
+    j.label_of_run = (int32_t*)w.label_of_run.p;
+    j.root_of_label = (int32_t*)w.root_of_label.p;
     j.cand_cap = (int32_t)((int64_t)H * W / lfa::kAreaMin + 1);
-    j.cand = (int32_t*)h->cand.p;
-    j.cand_sum = (unsigned long long*)h->cand_sum.p;
-    j.cand_rs_off = (int32_t*)h->cand_rs_off.p;
-    j.rowsum = (uint32_t*)h->rowsum.p;
+    j.cand = (int32_t*)w.cand.p;
+    j.cand_sum = (unsigned long long*)w.cand_sum.p;
+    j.cand_rs_off = (int32_t*)w.cand_rs_off.p;
+    j.rowsum = (uint32_t*)w.rowsum.p;
     j.rowsum_cap = 16 * H;
-    j.slot_rs_off = (int32_t*)h->slot_rs_off.p;
+    j.slot_rs_off = (int32_t*)w.slot_rs_off.p;
     j.lut8 = (const uint8_t*)h->lut8.p;
     j.lut16 = (const uint16_t*)h->lut16.p;
     return j;
@@ -271,7 +302,7 @@ lfa::Job make_job(LfaContext* h, const void* images, int dtype, int n, int H, in
 
 int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
                 int L, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
-                LfaRoi* out_rois, hipStream_t s, lfa::Job* job_out) {
+                LfaRoi* out_rois, hipStream_t s, lfa::Job* job_out, LfaRoi** ws_rois = nullptr) {
     int rc = check_images(h, images, dtype, n, H, W, C);
     if (rc) return rc;
     if (C == 3 && dtype != LFA_U8) return fail(LFA_ERR_UNSUPPORTED, "colour images must be uint8 (uint16 colour is not implemented)");
@@ -293,9 +324,16 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         }
         if (h->plane_host[7]) h->u16_plane_on = !h->pending_had_pred || 2u * h->plane_host[6] >= h->plane_host[7];
     }
-    // (after the counters: the workspace depends on the paths they select)
-    if ((rc = ensure_workspace(h, n, H, W, C, dtype, L, max_strips))) return rc;
-    lfa::Job j = make_job(h, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
+    lfa::Job j;
+    {
+        // (after the counters: the workspace depends on the paths they select)
+        if ((rc = ensure_workspace(h, n, H, W, C, dtype, L, max_strips))) return rc;
+        j = make_job(h, h->ws, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
+        // the handle's workspace is shared by its calls: a call on another stream than the last one waits for that one
+        if (h->have_done && s != h->last_stream) LFA_HIP(hipStreamWaitEvent(s, h->done_event, 0));
+        if (ws_rois) *ws_rois = (LfaRoi*)h->ws.rois.p;
+    }
+    if (!out_rois && ws_rois) out_rois = *ws_rois;          // lfa_analyze_batch without a caller's ROI buffer
     lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
     TimerScope ts(h);
     LFA_HIP(lfa::launch_threshold(j, s));
@@ -350,7 +388,13 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         lfa_destroy(h);
         return fail(LFA_ERR_HIP, "uploading gamma tables failed");
     }
+    // the whole workspace for calls within the handle's limits at the defaults (line_length >= 10, max_strips <= 64), class
+    // plane and big-image Otsu buffers included; lfa_reserve widens those two limits
     if ((rc = ensure_workspace(h, max_batch, max_h, max_w, max_c, LFA_U16, 10, 64))) { lfa_destroy(h); return rc; }
+    if (hipEventCreateWithFlags(&h->done_event, hipEventDisableTiming) != hipSuccess) {
+        h->done_event = nullptr; lfa_destroy(h);
+        return fail(LFA_ERR_HIP, "hipEventCreate failed");
+    }
     if ((rc = ensure(h->plane_stats, lfa::kStatsWords * 4))) { lfa_destroy(h); return rc; }
     if (hipHostMalloc((void**)&h->plane_host, lfa::kStatsWords * 4, hipHostMallocDefault) != hipSuccess) {
         h->plane_host = nullptr; lfa_destroy(h);
@@ -375,6 +419,7 @@ int lfa_destroy(LfaHandle h) {
     if (h->plane_event && h->plane_pending) (void)hipEventSynchronize(h->plane_event);   // the counters' copy reads plane_stats and writes plane_host
     for (Buf* b : h->all()) if (b->p) (void)hipFree(b->p);
     if (h->passes_event) (void)hipEventDestroy(h->passes_event);
+    if (h->done_event) (void)hipEventDestroy(h->done_event);
     if (h->plane_event) (void)hipEventDestroy(h->plane_event);
     if (h->plane_host) (void)hipHostFree(h->plane_host);
     delete h->timer;
@@ -417,8 +462,13 @@ int lfa_set_debug_flags(LfaHandle h, int flags) {
 int lfa_detect_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
                      int line_length, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
                      void* stream) {
-    return detect_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts,
-                       out_info, nullptr, (hipStream_t)stream, nullptr);
+    int rc = detect_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts,
+                         out_info, nullptr, (hipStream_t)stream, nullptr);
+    if (rc) return rc;
+    LFA_ON_DEVICE(h->device);
+    LFA_HIP(hipEventRecord(h->done_event, (hipStream_t)stream));
+    h->last_stream = (hipStream_t)stream; h->have_done = true;
+    return LFA_OK;
 }
 
 static int profile_impl(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, const LfaRoi* rois,
@@ -472,28 +522,48 @@ int lfa_peaks_batch(LfaHandle h, const double* profiles, const int32_t* lengths,
     return LFA_OK;
 }
 
-int lfa_analyze_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
-                      int line_length, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
-                      LfaRoi* out_rois, double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream) {
+static int analyze_impl(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
+                        int line_length, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
+                        LfaRoi* out_rois, double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream) {
     if (!out_profiles || !out_peaks) return fail(LFA_ERR_ARG, "null output pointer");
     if (profile_stride < 1) return fail(LFA_ERR_ARG, "profile_stride must be >= 1");
     lfa::Job j{};
-    // rois go to the caller's buffer or to the handle's own
-    int rc = check_images(h, images, dtype, n, H, W, C);
+    LfaRoi* ws_rois = nullptr;                  // the workspace's own ROI buffer, used when the caller passes none
+    int rc = detect_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts,
+                         out_info, out_rois, (hipStream_t)stream, &j, &ws_rois);
     if (rc) return rc;
-    if (max_strips < 1 || max_strips > 1024) return fail(LFA_ERR_ARG, "max_strips must be in [1,1024]");
+    if (!out_rois) out_rois = ws_rois;
     LFA_ON_DEVICE(h->device);
-    if (!out_rois) {
-        if ((rc = ensure(h->rois, (size_t)n * max_strips * sizeof(LfaRoi)))) return rc;
-        out_rois = (LfaRoi*)h->rois.p;
-    }
-    rc = detect_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts,
-                     out_info, out_rois, (hipStream_t)stream, &j);
-    if (rc) return rc;
     TimerScope ts(h);
     LFA_HIP(lfa::launch_profiles(j, out_rois, n * max_strips, out_counts, max_strips, j.slot_rs_off, 0, 15, out_profiles, profile_stride,
                                  out_peaks, nullptr, 0, nullptr, (hipStream_t)stream));
+    LFA_HIP(hipEventRecord(h->done_event, (hipStream_t)stream));
+    h->last_stream = (hipStream_t)stream; h->have_done = true;
     return LFA_OK;
+}
+
+int lfa_analyze_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
+                      int line_length, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
+                      LfaRoi* out_rois, double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream) {
+    return analyze_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts, out_info,
+                        out_rois, out_profiles, profile_stride, out_peaks, stream);
+}
+
+int lfa_reserve(LfaHandle h, int max_strips, int min_line_length) {
+    if (!h) return fail(LFA_ERR_ARG, "null handle");
+    if (max_strips < 1 || max_strips > 1024) return fail(LFA_ERR_ARG, "max_strips must be in [1,1024]");
+    if (min_line_length < 1) return fail(LFA_ERR_ARG, "min_line_length must be >= 1");
+    LFA_ON_DEVICE(h->device);
+    int rc = ensure_workspace(h, h->max_batch, h->max_h, h->max_w, h->max_c, LFA_U16, min_line_length, max_strips);
+    if (rc) return rc;
+    return ensure_workspace(h, h->max_batch, h->max_h, h->max_w, h->max_c, LFA_U8, min_line_length, max_strips);
+}
+
+int64_t lfa_workspace_bytes(LfaHandle h) {
+    if (!h) return 0;
+    int64_t total = 0;
+    for (Buf* b : h->all()) total += (int64_t)b->bytes;
+    return total;
 }
 
 int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, double sigma,

@@ -13,7 +13,9 @@
  *     unless a parameter is documented as host memory; images are C-contiguous, batch-major:
  *     image i starts at byte i * H*W*C*sizeof(pixel);
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls enqueue work and
- *     return without waiting unless documented otherwise; one handle per device and per host thread;
+ *     return without waiting unless documented otherwise; one handle per device and per host thread; a handle's
+ *     detect / analyze calls share its workspace, so they run in the order they were made even when they name
+ *     different streams (a call on another stream than the handle's previous call first waits for that call's event);
  *     a call makes the handle's device current while it runs and leaves the caller's current device as it found it;
  *   - nothing here reads or writes host memory behind the caller's back except the documented
  *     host-pointer parameters.
@@ -106,11 +108,22 @@ typedef struct {
 
 /* ---- lifetime ---------------------------------------------------------------------------------------------------- */
 
-/* Create a context on `device`.  max_h/max_w/max_c bound the images later calls may pass; max_batch bounds n per call.
- * Allocates all device workspace here (no allocation happens in the enqueue calls unless a later call exceeds these
- * limits, which is an error).  Builds the default gamma LUTs with the C library's pow().
+/* Create a context on `device`.  max_h/max_w/max_c bound the images later calls may pass; max_batch bounds n per call
+ * (a call beyond them fails with LFA_ERR_ARG).  Allocates here the whole device workspace of calls within those limits
+ * that keep line_length >= 10 and max_strips <= 64 (class plane and big-image Otsu buffers included), so such calls
+ * allocate nothing.  A call with a smaller line_length or a larger max_strips GROWS the workspace on the spot: the
+ * buffers concerned are released and allocated again with hipFree / hipMalloc, and hipFree waits for the whole device --
+ * call lfa_reserve first where that matters (a pipeline of several handles, a latency-bound loop).
+ * Builds the default gamma LUTs with the C library's pow().
  * Replaces: module import + the three globals of detection.py:25-28 (state lives in the handle instead). */
 int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHandle* out);
+/* Size the handle's workspace now for calls with max_strips up to `max_strips` and line_length down to
+ * `min_line_length` (at the handle's image and batch limits): after it, no detect / analyze call within those limits
+ * allocates or frees.  No counterpart in the reference. */
+int lfa_reserve(LfaHandle h, int max_strips, int min_line_length);
+/* Device bytes the handle holds right now (workspace + tables); a test hook: unchanged across a call = that call did not
+ * allocate.  No counterpart in the reference. */
+int64_t lfa_workspace_bytes(LfaHandle h);
 int lfa_destroy(LfaHandle h);
 const char* lfa_last_error(void);
 int lfa_version(void);

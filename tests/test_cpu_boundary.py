@@ -21,7 +21,7 @@ def capi():
 
 def test_every_declared_symbol_is_exported(capi):
     hdr = open(os.path.join(ROOT, "include", "lfa.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(lfa_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(lfa_\w+)\s*\(", hdr, flags=re.M))
     assert declared and declared == set(capi.EXPORTED), declared ^ set(capi.EXPORTED)
     for name in declared:
         assert getattr(capi.lib, name) is not None
