@@ -61,9 +61,11 @@ def _load():
     lib.lfa_profile_lut_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, vp]
     lib.lfa_peaks_batch.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.lfa_analyze_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]
+    lib.lfa_analyze_batch_static.argtypes = lib.lfa_analyze_batch.argtypes
     lib.lfa_reserve.argtypes = [vp, i32, i32]
     lib.lfa_workspace_bytes.argtypes = [vp]
     lib.lfa_workspace_bytes.restype = i64
+    lib.lfa_static_workspace_bytes.restype = i64
     lib.lfa_gaussian_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, dbl, vp, i32, vp, i32, vp]
     lib.lfa_debug_fetch.argtypes = [vp, i32, i32, vp, i64, vp]
     lib.lfa_sync.argtypes = [vp, vp]
@@ -72,7 +74,7 @@ def _load():
     lib.lfa_timing_read.argtypes = [vp, i32, vp, vp, vp, vp]
     for name in ("lfa_timing_enable", "lfa_timing_read","lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant", "lfa_detect_batch",
                  "lfa_profile_batch", "lfa_profile_lut_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch",
-                 "lfa_debug_fetch", "lfa_sync", "lfa_stream_wait_passes", "lfa_reserve"):
+                 "lfa_debug_fetch", "lfa_sync", "lfa_stream_wait_passes", "lfa_analyze_batch_static", "lfa_reserve"):
         getattr(lib, name).restype = i32
     return lib
 
@@ -83,7 +85,7 @@ EXPORTED = ("lfa_version", "lfa_last_error", "lfa_create", "lfa_destroy", "lfa_s
             "lfa_set_debug_flags",
             "lfa_detect_batch", "lfa_profile_batch", "lfa_profile_lut_batch", "lfa_peaks_batch", "lfa_analyze_batch",
             "lfa_gaussian_batch", "lfa_debug_fetch", "lfa_sync", "lfa_timing_enable", "lfa_timing_read",
-            "lfa_stream_wait_passes", "lfa_reserve",
+            "lfa_stream_wait_passes", "lfa_analyze_batch_static", "lfa_static_workspace_bytes", "lfa_reserve",
             "lfa_workspace_bytes")
 
 

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -87,7 +88,36 @@ struct EventTimer : lfa::KernelTimer {
 
 thread_local lfa::KernelTimer* lfa::g_timer = nullptr;
 
+// Workspace of lfa_analyze_batch_static: device memory that exists without any allocation call.  Every GPU the library
+// runs on holds its own copy of this array, at its own address, until the process ends.  In host code the NAME below is a
+// host-side stand-in, not a device address: host code uses the address hipGetSymbolAddress returns for the current
+// device (static_scratch_ptr, looked up once per device in lfa_create) -- never the name -- as kernel argument and in
+// hipMemsetAsync.
+static __device__ __align__(256) unsigned char scratch[LFA_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};      // per device: hipGetSymbolAddress(HIP_SYMBOL(scratch)) with that device current
+
+// call with `device` current
+int static_scratch_lookup(int device) {
+    if (device < 0 || device >= kMaxDevices) return LFA_OK;      // no static workspace beyond kMaxDevices devices (the entry point says so)
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[device]) return LFA_OK;
+    void* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+        g_err = std::string("hipGetSymbolAddress(scratch) on device ") + std::to_string(device) + ": " + hipGetErrorString(e);
+        return LFA_ERR_HIP;
+    }
+    g_scratch_ptr[device] = ptr;
+    return LFA_OK;
+}
+}  // namespace
+
 // Per-call device workspace of the detect path.  A handle owns one in hipMalloc memory (grown by ensure_workspace);
+// lfa_analyze_batch_static lays one out inside the library's static device array instead (carve_workspace).
 struct Workspace {
     Buf info, hist, otsu_w, otsu_s, edges, edges_i, bins, maskT, col_cnt, run_tmp, run_se, run_col, parent, area, bbox, rowcnt, rowpos, rootlist, bucket, label_of_run, root_of_label, cand,
         cand_sum, cand_rs_off, rowsum, slot_rs_off, rois;
@@ -300,9 +330,28 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
     return j;
 }
 
+// Lay a workspace out inside `base` (capacity bytes, 256-byte aligned pieces).  Returns the bytes it needs; the Bufs are
+// set only when that fits.  Allocates nothing.
+size_t carve_workspace(Workspace& w, unsigned char* base, size_t capacity, int n, int H, int W, int C, int dtype, int L, int max_strips) {
+    WsNeeds q = workspace_needs(w, n, H, W, C, dtype, L, max_strips, /*plane=*/false);
+    size_t off = 0;
+    for (int k = 0; k < q.n; ++k) off += (q.item[k].bytes + 255) & ~(size_t)255;
+    if (off > capacity) return off;
+    size_t at = 0;
+    for (int k = 0; k < q.n; ++k) {
+        q.item[k].b->p = base + at;
+        q.item[k].b->bytes = q.item[k].bytes;
+        at += (q.item[k].bytes + 255) & ~(size_t)255;
+    }
+    return off;
+}
+
+// static_ws: the workspace comes out of the library's static device array and the call allocates nothing -- no class
+// plane, no min/max-free uint16 histogram, no counters travelling back to the handle, no kernel timing (all of which
+// either need memory or are choices between paths with identical results).
 int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
                 int L, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
-                LfaRoi* out_rois, hipStream_t s, lfa::Job* job_out, LfaRoi** ws_rois = nullptr) {
+                LfaRoi* out_rois, hipStream_t s, lfa::Job* job_out, bool static_ws = false, LfaRoi** ws_rois = nullptr) {
     int rc = check_images(h, images, dtype, n, H, W, C);
     if (rc) return rc;
     if (C == 3 && dtype != LFA_U8) return fail(LFA_ERR_UNSUPPORTED, "colour images must be uint8 (uint16 colour is not implemented)");
@@ -325,7 +374,20 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         if (h->plane_host[7]) h->u16_plane_on = !h->pending_had_pred || 2u * h->plane_host[6] >= h->plane_host[7];
     }
     lfa::Job j;
-    {
+    if (static_ws) {
+        unsigned char* base = (h->device < kMaxDevices) ? (unsigned char*)g_scratch_ptr[h->device] : nullptr;
+        if (!base) return fail(LFA_ERR_UNSUPPORTED, "no static workspace on device %d (devices 0..%d have one)", h->device, kMaxDevices - 1);
+        Workspace w;
+        const size_t need = carve_workspace(w, base, (size_t)LFA_STATIC_SCRATCH_BYTES, n, H, W, C, dtype, L, max_strips);
+        if (need > (size_t)LFA_STATIC_SCRATCH_BYTES)
+            return fail(LFA_ERR_ARG, "lfa_analyze_batch_static: %d image(s) of %dx%dx%d with line_length %d and max_strips %d need %zu bytes of workspace, "
+                        "the static workspace holds LFA_STATIC_SCRATCH_BYTES = %zu; pass fewer or smaller images, or use lfa_analyze_batch",
+                        n, H, W, C, L, max_strips, need, (size_t)LFA_STATIC_SCRATCH_BYTES);
+        j = make_job(h, w, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
+        j.plane_stats = nullptr; j.bins = nullptr; j.u16_plane = 0; j.hist_abs = 0; j.win_hint = 0;
+        j.u16_lds_bins = lfa::kLdsBinsU16; j.u16_pred = 0; j.u16_pa = 0; j.u16_ps = 0;
+        if (ws_rois) *ws_rois = (LfaRoi*)w.rois.p;
+    } else {
         // (after the counters: the workspace depends on the paths they select)
         if ((rc = ensure_workspace(h, n, H, W, C, dtype, L, max_strips))) return rc;
         j = make_job(h, h->ws, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
@@ -335,7 +397,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     }
     if (!out_rois && ws_rois) out_rois = *ws_rois;          // lfa_analyze_batch without a caller's ROI buffer
     lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
-    TimerScope ts(h);
+    TimerScope ts(static_ws ? nullptr : h);
     LFA_HIP(lfa::launch_threshold(j, s));
     LFA_HIP(lfa::launch_mask(j, s));
     LFA_HIP(lfa::launch_label(j, s));
@@ -388,6 +450,7 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         lfa_destroy(h);
         return fail(LFA_ERR_HIP, "uploading gamma tables failed");
     }
+    if ((rc = static_scratch_lookup(device))) { lfa_destroy(h); return rc; }      // set-up of lfa_analyze_batch_static, once per device
     // the whole workspace for calls within the handle's limits at the defaults (line_length >= 10, max_strips <= 64), class
     // plane and big-image Otsu buffers included; lfa_reserve widens those two limits
     if ((rc = ensure_workspace(h, max_batch, max_h, max_w, max_c, LFA_U16, 10, 64))) { lfa_destroy(h); return rc; }
@@ -524,21 +587,23 @@ int lfa_peaks_batch(LfaHandle h, const double* profiles, const int32_t* lengths,
 
 static int analyze_impl(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
                         int line_length, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
-                        LfaRoi* out_rois, double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream) {
+                        LfaRoi* out_rois, double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream, bool static_ws) {
     if (!out_profiles || !out_peaks) return fail(LFA_ERR_ARG, "null output pointer");
     if (profile_stride < 1) return fail(LFA_ERR_ARG, "profile_stride must be >= 1");
     lfa::Job j{};
     LfaRoi* ws_rois = nullptr;                  // the workspace's own ROI buffer, used when the caller passes none
     int rc = detect_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts,
-                         out_info, out_rois, (hipStream_t)stream, &j, &ws_rois);
+                         out_info, out_rois, (hipStream_t)stream, &j, static_ws, &ws_rois);
     if (rc) return rc;
     if (!out_rois) out_rois = ws_rois;
     LFA_ON_DEVICE(h->device);
-    TimerScope ts(h);
+    TimerScope ts(static_ws ? nullptr : h);
     LFA_HIP(lfa::launch_profiles(j, out_rois, n * max_strips, out_counts, max_strips, j.slot_rs_off, 0, 15, out_profiles, profile_stride,
                                  out_peaks, nullptr, 0, nullptr, (hipStream_t)stream));
-    LFA_HIP(hipEventRecord(h->done_event, (hipStream_t)stream));
-    h->last_stream = (hipStream_t)stream; h->have_done = true;
+    if (!static_ws) {
+        LFA_HIP(hipEventRecord(h->done_event, (hipStream_t)stream));
+        h->last_stream = (hipStream_t)stream; h->have_done = true;
+    }
     return LFA_OK;
 }
 
@@ -546,8 +611,17 @@ int lfa_analyze_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
                       int line_length, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
                       LfaRoi* out_rois, double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream) {
     return analyze_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts, out_info,
-                        out_rois, out_profiles, profile_stride, out_peaks, stream);
+                        out_rois, out_profiles, profile_stride, out_peaks, stream, false);
 }
+
+int lfa_analyze_batch_static(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
+                             int line_length, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
+                             LfaRoi* out_rois, double* out_profiles, int profile_stride, LfaPeaks* out_peaks, void* stream) {
+    return analyze_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts, out_info,
+                        out_rois, out_profiles, profile_stride, out_peaks, stream, true);
+}
+
+int64_t lfa_static_workspace_bytes(void) { return (int64_t)LFA_STATIC_SCRATCH_BYTES; }
 
 int lfa_reserve(LfaHandle h, int max_strips, int min_line_length) {
     if (!h) return fail(LFA_ERR_ARG, "null handle");

@@ -210,6 +210,27 @@ int lfa_analyze_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
                       LfaRoi* out_rois, double* out_profiles, int profile_stride, LfaPeaks* out_peaks,
                       void* stream);
 
+/* lfa_analyze_batch for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results, but the per-call workspace lies in a
+ * file-scope device array of LFA_STATIC_SCRATCH_BYTES inside the library (each GPU the library runs on holds its own copy
+ * until the process ends; its address is looked up once per device in lfa_create), and the call makes no hipMalloc /
+ * hipFree / allocating library call, does no kernel timing and feeds nothing back to the handle's path choices (it always
+ * takes the plane-less, min/max-first paths, whose results are identical to the others').
+ *   - a batch whose workspace does not fit fails with LFA_ERR_ARG and a message naming the bytes needed; at the default
+ *     line_length 10 and max_strips 64 the array holds e.g. 4 images of 1536x2048x3, 3 frames of 2048x2048 uint16 or one
+ *     image of 3072x4096x3;
+ *     lfa_static_workspace_bytes() returns the capacity;
+ *   - every call on a GPU uses that GPU's one array: calls that overlap in time on one GPU (two streams, two handles, two
+ *     threads) RACE -- serialise them; the array keeps the last call's contents, each call clears what it needs zeroed;
+ *   - lfa_debug_fetch after it reads the static workspace (valid until the next static call on that GPU). */
+#define LFA_STATIC_SCRATCH_BYTES (64u << 20)
+int lfa_analyze_batch_static(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C,
+                             int min_maxr, int min_maxc, int line_length,
+                             LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
+                             LfaRoi* out_rois, double* out_profiles, int profile_stride, LfaPeaks* out_peaks,
+                             void* stream);
+int64_t lfa_static_workspace_bytes(void);
+
 /* ---- gaussian: skimage.filters.gaussian(image, sigma) -- skimage/_shared/filters.py:35-166, caller detection.py:166 ---- */
 
 /* Separable Gaussian, mode='nearest', truncate=4.0, on img_as_float(image) (uint8: x*(1/255), uint16: x*(1/65535)),
