@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- LFA strips analysed per second (detect + profile + peaks) on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
+        N = 1: runs here.  N > 1 without a launcher's WORLD_SIZE: starts `python -m torch.distributed.run --nnodes=1
+        --nproc-per-node N --master-addr 127.0.0.1 ...` on itself as a child -- before anything touches the GPU -- and
+        relays its output.  Under a launcher (RANK / LOCAL_RANK / WORLD_SIZE set) WORLD_SIZE must equal --gpus.
 
-Workload (BASELINE.json configs[1]): a batch of 1024 synthetic 2048x1536 colour images, 8 strips each, per GPU,
-resident in HBM before the timed region.  A step = one pass of lfa_analyze_batch over that batch (in chunks of
---chunk images).  The batch is a pool of --pool distinct seeded images (image_analysis_amd.synth.synth_rgb) tiled on the
-device.  Multi-GPU: every rank owns its own batch (weak scaling, no data-path collective); the strip counts are
-summed with one all_reduce after the timed region.
+Headline workload (BASELINE.json configs[1]): a batch of 1024 synthetic 2048x1536 colour images, 8 strips each, per GPU,
+resident in HBM before the timed region.  A step = one pass of lfa_analyze_batch over that batch (in chunks of --chunk
+images alternating over --streams handles).  The batch is a pool of --pool distinct seeded images
+(image_analysis_amd.synth.synth_rgb) tiled on the device.  Multi-GPU: every rank owns its own batch (weak scaling, no
+data-path collective); after the timed region the per-strip result records of all ranks are gathered once over the
+collective backend (RCCL; `shard.gather_strip_records`), as north_star's "final result gather".
 
 One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel of the step (found in warm-up with every
 kernel timed, then timed alone with HIP events inside the timed region); its algorithmic bytes are the image bytes one
-launch reads.  `cpu_baseline` is the oracle (numpy/scipy port of the reference arithmetic) on a bounded
-sample of the same images on the host: a pool of processes (`cores`), with the one-core figure beside it.
+launch reads plus what it must write.  `cpu_baseline` is the oracle (numpy/scipy restatement of the reference
+arithmetic) on a bounded sample of the same images on the host.  `configs` holds the other BASELINE.json configurations,
+measured after the headline region in the same process: configs[3] (3072x4096 images; at every N, with its own record
+gather) and, at N = 1, configs[2], the reference's own 16-bit frame, configs[4] and the Gaussian stage.
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -46,6 +51,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=2, help="HIP streams (one LfaHandle each) the chunks alternate on")
     ap.add_argument("--stagger", type=int, default=0, help="1: a chunk's image passes start when the previous chunk's histogram pass is done")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary configurations (the `configs` object)")
+    ap.add_argument("--config-steps", type=int, default=10, help="timed steps of each secondary configuration")
     return ap.parse_args()
 
 
@@ -58,14 +65,13 @@ def merge_times(dicts):
     return out
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, pool_run=True):
     """The oracle on a bounded sample of the workload, in a child process of its own (oracle/cpu_baseline.py), run to
-    completion BEFORE this process initialises the GPU: one core, then a pool of processes."""
-    import subprocess
+    completion BEFORE this process initialises the GPU: one core, then (pool_run) a pool of processes."""
     procs = args.cpu_procs or min(16, os.cpu_count() or 1)
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--height", str(args.height), "--width", str(args.width),
-           "--pool", str(args.pool), "--seed0", "1234", "--single", str(args.cpu_sample), "--parallel", str(args.cpu_sample * 8),
-           "--procs", str(procs)]
+           "--pool", str(args.pool), "--seed0", "1234", "--single", str(args.cpu_sample),
+           "--parallel", str(args.cpu_sample * 8 if pool_run else 0), "--procs", str(procs)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         raise RuntimeError("cpu baseline failed: " + r.stderr[-2000:])
@@ -81,12 +87,51 @@ def cpu_baseline(args):
     return cpu
 
 
+def self_launch(args):
+    """--gpus N > 1 without a launcher: become the launcher.  Nothing in this process has touched the GPU yet."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def strip_records(capi, strips_t, counts_np, peaks_t, max_strips, image0):
+    """The fixed-size per-strip result record of every strip of this rank: image index, box, area, label, the peaks."""
+    B = len(counts_np)
+    st = capi.from_device(strips_t, capi.STRIP_DT, B * max_strips).reshape(B, max_strips)
+    pk = capi.from_device(peaks_t, capi.PEAKS_DT, B * max_strips).reshape(B, max_strips)
+    dt = np.dtype([("image", "<i4"), ("strip", capi.STRIP_DT), ("peaks", capi.PEAKS_DT)])
+    rec = np.zeros(int(counts_np.sum()), dtype=dt)
+    k = 0
+    for i in range(B):
+        c = int(counts_np[i])
+        rec["image"][k:k + c] = image0 + i
+        rec["strip"][k:k + c] = st[i, :c]
+        rec["peaks"][k:k + c] = pk[i, :c]
+        k += c
+    return rec
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        return self_launch(args)
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    cpu = cpu_baseline(args) if (args.cpu_sample > 0 and world == 1 and rank == 0) else None
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree\n")
+        return 2
+    # the oracle on the host, before this process initialises the GPU: whole sample at N = 1; at N > 1 rank 0 times the
+    # one-core sample only (a 16-process pool would compete with the other ranks' host threads)
+    cpu = None
+    if args.cpu_sample > 0 and rank == 0:
+        cpu = cpu_baseline(args, pool_run=(world == 1))
 
     import torch
     import torch.distributed as dist
@@ -102,10 +147,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    cdev = torch.device("cpu") if rehearsal else dev          # where the few collective operands live
+    cdev = torch.device("cpu") if rehearsal else dev          # where the collective operands live
 
     capi = importlib.import_module("image_analysis_amd._capi")
     synth = importlib.import_module("image_analysis_amd.synth")
+    shard = importlib.import_module("image_analysis_amd.shard")
 
     H, W, C = args.height, args.width, 3
     B, CH = args.batch, min(args.chunk, args.batch)
@@ -127,7 +173,6 @@ def main():
     # the streaming kernels of the next (per-device streams, no cross-stream dependency: chunks are independent)
     NS = max(1, min(args.streams, (B + CH - 1) // CH))
     engs = [capi.Engine(device=dev_index, max_h=H, max_w=W, max_c=3, max_batch=CH) for _ in range(NS)]
-    eng = engs[0]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     strips = capi.dev_bytes(B * max_strips * capi.STRIP_DT.itemsize, dev)
     counts = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -157,6 +202,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        tt = torch.tensor([seconds], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def sum_over_ranks(value):
+        if world == 1:
+            return int(value)
+        tt = torch.tensor([int(value)], dtype=torch.int64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        return int(tt.item())
+
+    def gather_records(strips_t, counts_t, peaks_t, ms, n_local):
+        """every rank ends with the records of all world*n_local images in image order; returns (records, seconds)"""
+        torch.cuda.synchronize()
+        cn = counts_t.cpu().numpy()
+        rec = strip_records(capi, strips_t, cn, peaks_t, ms, rank * n_local)
+        barrier()
+        t0 = time.perf_counter()
+        all_counts, all_rec = shard.gather_strip_records(cn, rec, world * n_local, device=cdev)
+        barrier()
+        return all_counts, all_rec, max_over_ranks(time.perf_counter() - t0)
+
     torch.cuda.synchronize()                             # inputs are resident before any chunk stream starts
 
     # ---- warm-up; with every kernel timed, to find the dominant one ----
@@ -179,11 +249,7 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
 
     ktimes = merge_times([e.timing_read() for e in engs]) if dominant else {}
     step_times = {}
@@ -196,20 +262,43 @@ def main():
     for e in engs:
         e.timing(None)
 
-    # ---- results of one step ----
+    # ---- results of one step; the final gather of the per-strip records (the path's only collective) ----
     inf = capi.from_device(info, capi.INFO_DT, B)
     assert (inf["status"] == 0).all(), "strip capacity overflow"
-    n_strips = counts.sum().to(torch.int64)
     amb = int(inf["ambiguous"].sum())
-    pk = capi.from_device(peaks, capi.PEAKS_DT, B * max_strips).reshape(B, max_strips)
-    cn = counts.cpu().numpy()
-    n_peaks = int(sum(int(pk[i, :cn[i]]["n_peaks"].sum()) for i in range(0, B, max(1, B // 64))))
-    if world > 1:
-        n_strips = n_strips.to(cdev)
-        dist.all_reduce(n_strips, op=dist.ReduceOp.SUM)
-    total_strips = int(n_strips.item())
+    all_counts, all_rec, gather_s = gather_records(strips, counts, peaks, max_strips, B)
+    total_strips = int(all_counts.sum())
+    assert total_strips == sum_over_ranks(int(counts.sum().item())) and len(all_rec) == total_strips
+    assert len(all_counts) == world * B and (np.diff(all_rec["image"]) >= 0).all()
+    n_peaks = int(all_rec["peaks"]["n_peaks"].sum())
+    for e in engs:
+        e.close()
+    del batch, profiles
+    torch.cuda.empty_cache()
 
-    out = None
+    # ---- the other configurations, after the headline region (the `configs` object) ----
+    configs = None
+    if not args.no_configs:
+        bc = importlib.import_module("benchmarks_configs")
+        configs = {}
+        r = bc.bench_big(steps=args.config_steps, seed0=77 + 4 * rank, keep_pipeline=True, barrier=barrier if world > 1 else None)
+        pl = r.pop("_pipeline")
+        dt3 = max_over_ranks(r["ms_per_step"] * 1e-3)
+        s3 = sum_over_ranks(r["strips_per_step"])
+        c3, rec3, g3 = gather_records(pl.strips, pl.counts, pl.peaks, pl.ms, pl.B)
+        assert int(c3.sum()) == s3 == len(rec3)
+        pl.close()
+        del pl
+        torch.cuda.empty_cache()
+        r.update({"n_gpus": world, "scaling": "weak", "ms_per_step": round(dt3 * 1e3, 3),
+                  "images_per_s": round(world * r["images"] / dt3, 1), "strips_per_s": round(s3 / dt3, 1), "strips_per_step": s3,
+                  "e2e_frac_hbm": round(r["images"] / dt3 * 3072 * 4096 * 3 / (HBM_PEAK_GBS * 1e9), 4),
+                  "gather": {"records": len(rec3), "record_bytes": rec3.dtype.itemsize, "seconds": round(g3, 5),
+                             "backend": "gloo (rehearsal)" if rehearsal else ("rccl" if world > 1 else "none (one rank)")}})
+        configs["configs[3]"] = r
+        if world == 1:
+            configs.update(bc.secondary(steps=args.config_steps))
+
     if rank == 0:
         value = total_strips * args.steps / dt
         images_s = world * B * args.steps / dt
@@ -223,22 +312,26 @@ def main():
             npx = H * W
             per_image = {"k_minmax_rgb": npx * 3,                 # image in
                          "k_hist_rgb": npx * 3 + npx // 2,         # image in, class plane out (4 bits per pixel)
+                         "k_front_rgb": npx * 3 + npx // 2,
                          "k_mask": npx // 2 + npx // 8}.get(dominant, img_bytes)   # class plane in, bit mask out
             alg_bytes = CH * per_image
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-            traffic = None
+            traffic, traffic_source = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")       # HBM bytes per launch from rocprofv3 --pmc passes
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 key = f"{dominant}:{H}x{W}x{C}:chunk{CH}"
                 traffic = tj.get(key)
+                if traffic is not None:
+                    traffic_source = tj.get("_source", "profiles/traffic.json")
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
                     "note": f"timed region runs {NS} chunk streams: a launch shares the CUs with the other stream's passes and "
                             "tail kernels, so `frac` says how much else ran beside the kernel, not how well it uses the memory "
-                            "system; `isolated` is the same kernel in one extra untimed step on a single stream "
-                            "(--stagger 1 keeps the pass alone in the timed region: frac 0.56, throughput -5 %)"}
+                            "system; `isolated` is the same kernel in one extra untimed step on a single stream; `traffic` is "
+                            "not measured in this run: it is the PMC figure (2*FETCH_SIZE + WRITE_SIZE, KiB units) of the "
+                            "rocprofv3 passes named in `traffic_source`"}
             if dominant in step_times and step_times[dominant][1] > 0:
                 iso_ms = step_times[dominant][0] / step_times[dominant][1]
                 roof["isolated"] = {"avg_launch_ms": round(iso_ms, 4), "achieved": round(alg_bytes / (iso_ms * 1e-3) / 1e9, 1),
@@ -249,16 +342,18 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: {B} synthetic {W}x{H} RGB uint8 images per GPU, 8 strips each, "
                                    f"end-to-end detect+profile+peaks", "images_per_gpu": B, "chunk": CH, "streams": NS, "pool": args.pool,
-                       "min_maxr": mm_r, "min_maxc": mm_c, "parallelism": f"images sharded over {world} GPU(s), no collective on the data path"},
+                       "min_maxr": mm_r, "min_maxc": mm_c, "parallelism": f"images sharded over {world} GPU(s), no collective on the data path; "
+                                                                           "one gather of the per-strip records after the timed region"},
             "images_per_s": round(images_s, 1), "strips_per_step": total_strips,
             "e2e_fraction_of_hbm_roofline": round(images_s / world * img_bytes / (HBM_PEAK_GBS * 1e9), 4),
-            "ambiguous_pixels": amb, "peaks_in_sample": n_peaks,
+            "ambiguous_pixels": amb, "peaks_in_gathered_records": n_peaks,
+            "gather": {"records": len(all_rec), "record_bytes": all_rec.dtype.itemsize, "seconds": round(gather_s, 5),
+                       "backend": "gloo (rehearsal)" if rehearsal else ("rccl" if world > 1 else "none (one rank)")},
             "roofline": roof, "cpu_baseline": cpu,
             "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(step_times.items(), key=lambda kv: -kv[1][0])},
+            "configs": configs,
         }
         print(json.dumps(out), flush=True)
-    for e in engs:
-        e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -292,7 +292,7 @@ class Engine:
     def profile_raw(self, images_t, dtype_code, n, H, W, Cc, rois_t, n_rois, inverse, rng, stride, luts_t=None, n_luts=0,
                     roi_lut_t=None):
         torch = _torch()
-        profiles = torch.empty(max(n_rois, 1) * stride, dtype=torch.float64, device=self.device)
+        profiles = torch.zeros(max(n_rois, 1) * stride, dtype=torch.float64, device=self.device)
         peaks = dev_bytes(max(n_rois, 1) * PEAKS_DT.itemsize, self.device)
         if luts_t is None:
             _check(lib.lfa_profile_batch(self._h, images_t.data_ptr(), dtype_code, n, H, W, Cc, rois_t.data_ptr(), n_rois,
@@ -342,6 +342,39 @@ class Engine:
             out_i.append(inf.copy())
         return out_s, np.concatenate(out_i)
 
+    @staticmethod
+    def unpack_analysis(n, max_strips, stride, strips, counts, info, profiles, peaks):
+        """Host arrays of one analyze_raw call -> (per image (strips, [profile...], peaks), INFO_DT array); None for the first
+        element when an image overflowed max_strips (status bit 0: the caller re-runs with more)."""
+        inf = info[: n * INFO_DT.itemsize].view(INFO_DT)
+        if (inf["status"] & ~1).any():
+            raise LfaError(-3, f"analyze overflow (status {inf['status'].tolist()}): run capacity exceeded")
+        if (inf["status"] & 1).any():
+            return None, inf
+        cn = counts[: n * 4].view(np.int32)
+        st = strips[: n * max_strips * STRIP_DT.itemsize].view(STRIP_DT).reshape(n, max_strips)
+        pk = peaks[: n * max_strips * PEAKS_DT.itemsize].view(PEAKS_DT).reshape(n, max_strips)
+        pr = profiles.reshape(n, max_strips, stride)
+        res = []
+        for i in range(n):
+            k = int(cn[i])
+            res.append((st[i, :k].copy(), [pr[i, q, :pk[i, q]["length"]].copy() for q in range(k)], pk[i, :k].copy()))
+        return res, inf
+
+    def analyze_device(self, images_t, dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length, max_strips, stride):
+        """analyze_raw on a resident batch + the same ladder as `detect`: an image with more accepted regions than
+        max_strips (status bit 0) sends the batch round again with 4x the slots, up to the ABI's 1024."""
+        ms = int(max_strips)
+        while True:
+            out = self.analyze_raw(images_t, dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length, ms, stride)
+            strips, counts, info, _rois, profiles, peaks = [t.cpu().numpy() for t in out]
+            res, inf = self.unpack_analysis(n, ms, stride, strips, counts, info, profiles, peaks)
+            if res is not None:
+                return res, inf.copy()
+            if ms >= 1024:
+                raise LfaError(-3, f"analyze overflow (status {inf['status'].tolist()}): more than 1024 strips per image")
+            ms = min(1024, ms * 4)
+
     def analyze(self, images: np.ndarray, min_maxr, min_maxc, line_length=10, max_strips=64):
         """detect + image_analysis(strip, False) per strip.  Returns per image: (strips, [profile...], PEAKS_DT array)."""
         images, n, H, W, Cc, code = self._prep(images)
@@ -350,21 +383,11 @@ class Engine:
         infos = []
         for b0 in range(0, n, self.max_batch):
             b1 = min(n, b0 + self.max_batch)
-            nb = b1 - b0
             t = to_device(images[b0:b1], self.device)
-            strips, counts, info, rois, profiles, peaks = self.analyze_raw(t, code, nb, H, W, Cc, int(min_maxr),
-                                                                           int(min_maxc), int(line_length), max_strips, stride)
-            inf = from_device(info, INFO_DT, nb)
-            if (inf["status"] != 0).any():
-                raise LfaError(-3, f"analyze overflow (status {inf['status'].tolist()}); raise max_strips")
-            cn = from_device(counts, np.int32, nb)
-            st = from_device(strips, STRIP_DT, nb * max_strips).reshape(nb, max_strips)
-            pk = from_device(peaks, PEAKS_DT, nb * max_strips).reshape(nb, max_strips)
-            pr = profiles.cpu().numpy().reshape(nb, max_strips, stride)
-            for i in range(nb):
-                k = cn[i]
-                res.append((st[i, :k].copy(), [pr[i, q, :pk[i, q]["length"]].copy() for q in range(k)], pk[i, :k].copy()))
-            infos.append(inf.copy())
+            r, inf = self.analyze_device(t, code, b1 - b0, H, W, Cc, int(min_maxr), int(min_maxc), int(line_length),
+                                         max_strips, stride)
+            res += r
+            infos.append(inf)
         return res, np.concatenate(infos)
 
     def profiles(self, images: np.ndarray, rois: np.ndarray, inverse=False, rng=15, luts=None, roi_lut=None):
@@ -379,6 +402,10 @@ class Engine:
         n_rois = len(rois)
         if n_rois == 0:
             return [], np.zeros(0, PEAKS_DT)
+        bad = ((rois["image"] < 0) | (rois["image"] >= n) | (rois["r0"] < 0) | (rois["c0"] < 0) | (rois["r1"] > H) |
+               (rois["c1"] > W * Cc) | (rois["r1"] < rois["r0"]) | (rois["c1"] < rois["c0"]))
+        if bad.any():
+            raise ValueError(f"ROI {int(np.flatnonzero(bad)[0])} lies outside its image or is inverted: {rois[bad][0]}")
         stride = max(1, int((rois["r1"] - rois["r0"]).max()))
         t = to_device(images, self.device)
         rt = to_device(rois, self.device)
@@ -395,9 +422,13 @@ class Engine:
                 roi_lut = np.ascontiguousarray(roi_lut, dtype=np.int32)
                 if roi_lut.shape != (n_rois,):
                     raise ValueError("roi_lut needs one table index per ROI")
+                if ((roi_lut < 0) | (roi_lut >= n_luts)).any():
+                    raise ValueError(f"roi_lut holds a table index outside [0, {n_luts})")
                 rlt = to_device(roi_lut, self.device)
         profiles, peaks = self.profile_raw(t, code, n, H, W, Cc, rt, n_rois, inverse, rng, stride, lt, n_luts, rlt)
         pk = from_device(peaks, PEAKS_DT, n_rois)
+        if (pk["n_peaks"] < 0).any():                      # the kernel's own bad-ROI mark (lfa.h): no profile was written
+            raise LfaError(-1, f"ROI {int(np.flatnonzero(pk['n_peaks'] < 0)[0])} was rejected by the device")
         pr = profiles.cpu().numpy().reshape(n_rois, stride)
         return [pr[i, :max(0, pk[i]["length"])].copy() for i in range(n_rois)], pk.copy()
 

@@ -190,24 +190,59 @@ def analyze_peaks(profile, inverse=False, window_size=25):
 
 
 # ---- batch entry points (new: SURVEY.md section 3.4; the reference handles one image and one strip at a time) --------
-def analyze_batch(images, line_length=10, max_batch=16, device=None):
+def analyze_batch(images, line_length=10, max_batch=16, device=None, max_strips=64, devices=None):
     """detect + image_analysis(strip, False) for every strip of every image of a (n,H,W[,3]) batch.
 
     Uses the module globals min_maxr / min_maxc exactly like detect_lateral_flow_tests.  Returns one entry per image:
-    a list of (crop_view, profile, peaks) in the order detect_lateral_flow_tests returns the crops."""
+    a list of (crop_view, profile, peaks) in the order detect_lateral_flow_tests returns the crops.  max_strips is the
+    number of result slots per image to start with; an image with more accepted strips re-runs its batch with 4x the
+    slots (up to 1024), so the value only matters for speed and memory.
+
+    devices=[d0, d1, ...]: the batch is cut into contiguous blocks, one per entry (`shard.shard_range`; image i goes to
+    entry i*len(devices)//n), and every block runs on its device with its own handle, its own pair of HIP streams and its
+    own host thread (`frames.analyze_stream`: pinned, double-buffered uploads, batches of max_batch); the per-image results
+    are joined on the host in image order.  Images are independent, so no device talks to another.  The
+    same device may be named more than once (two handles, two stream pairs on one GPU)."""
     images = np.asanyarray(images)
     if images.ndim not in (3, 4) or (images.ndim == 4 and images.shape[-1] != 3):
         raise ValueError("expected a batch (n,H,W) or (n,H,W,3)")
     _check_pixels(images)
-    dev = _DEVICE if device is None else int(device)
-    eng = _capi.Engine(device=dev, max_h=images.shape[1], max_w=images.shape[2], max_c=3, max_batch=max_batch)
-    try:
-        res, _info = eng.analyze(images, int(min_maxr), int(min_maxc), int(line_length))
-    finally:
-        eng.close()
+    if devices is not None:
+        res = _analyze_sharded(images, [int(d) for d in devices], int(line_length), int(max_batch), int(max_strips))
+    else:
+        dev = _DEVICE if device is None else int(device)
+        eng = _capi.Engine(device=dev, max_h=images.shape[1], max_w=images.shape[2], max_c=3, max_batch=max_batch)
+        try:
+            res, _info = eng.analyze(images, int(min_maxr), int(min_maxc), int(line_length), max_strips=int(max_strips))
+        finally:
+            eng.close()
     out = []
     for i, (strips, profiles, peaks) in enumerate(res):
         img = images[i]
         out.append([(img[int(s["minr"]):int(s["maxr"]), int(s["minc"]):int(s["maxc"])], profiles[k], _peaks_to_list(peaks[k]))
                     for k, s in enumerate(strips)])
     return out
+
+
+def _analyze_sharded(images, devices, line_length, max_batch, max_strips):
+    """One host thread per entry of `devices`, each streaming its contiguous block of the batch through its own handle."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import frames, shard
+    if not devices:
+        raise ValueError("devices must name at least one GPU")
+    n, world = len(images), len(devices)
+    mm_r, mm_c = int(min_maxr), int(min_maxc)
+    pack = max(1, 16 // world)
+
+    def run(k):
+        lo, hi = shard.shard_range(n, k, world)
+        got = list(frames.analyze_stream((images[i] for i in range(lo, hi)), batch=max_batch, device=devices[k],
+                                         line_length=line_length, max_strips=max_strips, min_maxr=mm_r, min_maxc=mm_c,
+                                         pack_threads=pack))
+        assert [g[0] for g in got] == list(range(hi - lo))
+        return [g[1:] for g in got]
+
+    with ThreadPoolExecutor(max_workers=world) as ex:
+        blocks = list(ex.map(run, range(world)))                   # in shard order = image order
+    return [r for blk in blocks for r in blk]

@@ -115,17 +115,14 @@ def analyze_stream(frames, batch=16, device=0, line_length=10, max_strips=64, mi
         slot["done"].synchronize()
         n, index0 = slot["n"], slot["index0"]
         strips, counts, info, _rois, profiles, peaks = [t.numpy() for t in slot["host_out"]]
-        inf = info[: n * _capi.INFO_DT.itemsize].view(_capi.INFO_DT)
-        if (inf["status"] != 0).any():
-            raise _capi.LfaError(-3, f"analyze overflow (status {inf['status'].tolist()}); raise max_strips")
-        cn = counts[: n * 4].view(np.int32)
-        st = strips[: n * max_strips * _capi.STRIP_DT.itemsize].view(_capi.STRIP_DT).reshape(n, max_strips)
-        pk = peaks[: n * max_strips * _capi.PEAKS_DT.itemsize].view(_capi.PEAKS_DT).reshape(n, max_strips)
-        pr = profiles.reshape(n, max_strips, stride)
-        res = []
-        for i in range(n):
-            k = int(cn[i])
-            res.append((index0 + i, st[i, :k].copy(), [pr[i, q, :pk[i, q]["length"]].copy() for q in range(k)], pk[i, :k].copy()))
+        per_image, _inf = _capi.Engine.unpack_analysis(n, max_strips, stride, strips, counts, info, profiles, peaks)
+        if per_image is None:
+            # an image with more than max_strips accepted regions: this batch goes round again with more slots (the frames
+            # are still in the slot's device buffer), like Engine.detect / Engine.analyze
+            with torch.cuda.stream(comp_s):
+                per_image, _inf = eng.analyze_device(slot["dev"], code, n, H, W, Cc, mm_r, mm_c, int(line_length),
+                                                     min(1024, max_strips * 4), stride)
+        res = [(index0 + i, *per_image[i]) for i in range(n)]
         slot["busy"] = False
         slot["out"] = slot["host_out"] = None
         return res

@@ -1,0 +1,48 @@
+"""bench.py's launch contract: --gpus N must agree with the launcher's WORLD_SIZE, starts N ranks itself when there is no
+launcher, and prints one JSON line with the keys the driver reads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "1", "--warmup", "1", "--cpu-sample", "0", "--batch", "16", "--chunk", "8", "--pool", "2",
+         "--height", "384", "--width", "512", "--no-configs"]
+
+
+def test_gpus_flag_must_agree_with_the_launcher():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "must agree" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_one_rank_line_has_the_contract_keys():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SMALL, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "gather"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and "workload" in d["config"]
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
+    assert d["gather"]["records"] == d["strips_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_started_by_bench_itself_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts torch.distributed.run on itself.  LFA_BENCH_REHEARSAL=1 lets the two
+    ranks share this box's one GPU and talk over gloo; the real run is one rank per GPU over RCCL (same code path otherwise:
+    rank-dependent inputs, barrier + max-over-ranks timing, gather of the per-strip records)."""
+    env = dict(os.environ, LFA_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["gather"]["records"] == d["strips_per_step"] > 0 and d["gather"]["backend"].startswith("gloo")

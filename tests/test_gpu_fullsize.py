@@ -143,3 +143,81 @@ def test_two_handles_chained_with_stream_wait_passes():
             assert pk_np[i, k] == w_peaks[k]
     for e in engs:
         e.close()
+
+
+def _many_strips_image(seed=0, rows=6, cols=16):
+    """rows x cols small bright blocks (14 x 12 px, area 168 >= 100) on a dark ground, far enough apart that no two
+    boxes touch: with the module defaults min_maxr = min_maxc = 0 every one of them is an accepted strip."""
+    rng = np.random.default_rng(seed)
+    img = rng.integers(10, 30, size=(rows * 40 + 8, cols * 32 + 8), dtype=np.uint8)
+    for r in range(rows):
+        for c in range(cols):
+            img[8 + r * 40: 22 + r * 40, 8 + c * 32: 20 + c * 32] = rng.integers(200, 250, size=(14, 12))
+    return img
+
+
+def test_more_than_64_strips_through_the_batch_api(monkeypatch):
+    """An image with 96 accepted strips: Engine.analyze / detection.analyze_batch / frames.analyze_stream start with 64 result
+    slots per image and re-run the batch with more when an image overflows them, like detect always did."""
+    import image_analysis_amd.detection as det
+    from image_analysis_amd import frames as F
+    img = _many_strips_image()
+    few = img.copy()
+    few[:, 200:] = 15                                     # a batch-mate with fewer strips
+    d = O.detect_debug(img, 0, 0)
+    assert len(d["strips"]) == 96
+    monkeypatch.setattr(det, "min_maxr", 0)
+    monkeypatch.setattr(det, "min_maxc", 0)
+    out = det.analyze_batch(np.stack([few, img]), max_batch=2)
+    assert len(out[1]) == 96 and 0 < len(out[0]) < 64
+    for i, im in enumerate((few, img)):
+        want = O.detect_debug(im, 0, 0)["strips"]
+        assert len(out[i]) == len(want)
+        for (crop, prof, peaks), (a, b, c, e) in zip(out[i], want):
+            assert np.array_equal(crop, im[a:b, c:e])
+            wp, wk = O.image_analysis(im[a:b, c:e], False)
+            assert np.array_equal(prof, wp) and [(p[0], p[1]) for p in peaks] == [(s0, e0) for s0, e0, _ in wk]
+    assert len(det.analyze_batch(img[None], max_strips=8)[0]) == 96           # 8 -> 32 -> 128 slots
+    got = list(F.analyze_stream(iter([few, img, few]), batch=2, min_maxr=0, min_maxc=0))
+    assert [len(g[1]) for g in got] == [len(out[0]), 96, len(out[0])]
+
+
+def test_bad_rois_are_refused_not_returned_as_garbage():
+    import image_analysis_amd._capi as capi
+    eng = capi.Engine(device=0, max_h=64, max_w=64, max_batch=1)
+    try:
+        img = np.zeros((1, 32, 32), np.uint8)
+        roi = np.zeros(1, dtype=capi.ROI_DT)
+        for r0, r1, c0, c1, im in ((0, 40, 0, 8, 0), (5, 4, 0, 8, 0), (0, 8, 0, 8, 1), (0, 8, -1, 8, 0)):
+            roi["r0"], roi["r1"], roi["c0"], roi["c1"], roi["image"] = r0, r1, c0, c1, im
+            with pytest.raises(ValueError):
+                eng.profiles(img, roi)
+        roi["r0"], roi["r1"], roi["c0"], roi["c1"], roi["image"] = 0, 8, 0, 8, 0
+        with pytest.raises(ValueError):
+            eng.profiles(img, roi, luts=np.arange(256, dtype=np.uint8), roi_lut=np.array([3], np.int32))
+    finally:
+        eng.close()
+
+
+def test_sharded_analyze_batch_two_handles_equal_one(monkeypatch):
+    """detection.analyze_batch(images, devices=[0, 0]): two contiguous shards, each with its own handle, stream pair and host
+    thread (here both on GPU 0 -- the box has one), joined in image order; must equal the single-handle result and the oracle."""
+    import image_analysis_amd.detection as det
+    from image_analysis_amd.synth import synth_rgb
+    imgs = np.stack([synth_rgb(384, 512, 6, 500 + i) for i in range(7)])            # 7 images: shards of 3 and 4
+    mm_c = int(512 / 40)
+    monkeypatch.setattr(det, "min_maxc", mm_c)
+    monkeypatch.setattr(det, "min_maxr", mm_c * 20)
+    one = det.analyze_batch(imgs, max_batch=4)
+    for devices in ([0, 0], [0, 0, 0], [0]):
+        two = det.analyze_batch(imgs, max_batch=2, devices=devices)
+        assert len(two) == len(one) == 7
+        for a, b in zip(one, two):
+            assert len(a) == len(b) > 0
+            for (c1, p1, k1), (c2, p2, k2) in zip(a, b):
+                assert np.array_equal(c1, c2) and c1.base is not None and np.array_equal(p1, p2) and k1 == k2
+    for i in (0, 6):
+        want = O.detect_debug(imgs[i], mm_c * 20, mm_c)["strips"]
+        assert [c.shape[:2] for c, _p, _k in one[i]] == [(min(b, 384) - a, min(e, 512) - c) for a, b, c, e in want]
+    with pytest.raises(ValueError):
+        det.analyze_batch(imgs, devices=[])

@@ -9,7 +9,7 @@ timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout
 tail -2 gpurun_out/round_tests.log
 timeout -k 10 300 python bench.py > gpurun_out/round_bench.log 2>&1
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/round_prof -o r --output-format csv -- python3 $R/bench.py > $R/gpurun_out/round_prof_bench.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/round_prof -o r --output-format csv -- python3 $R/bench.py --cpu-sample 0 --no-configs > $R/gpurun_out/round_prof_bench.log 2>&1
 cd $R
 bash tools/pmc_passes.sh > gpurun_out/round_pmc.log 2>&1
 # one process per configuration: measured in one process after another configuration, configs[3] came out 14 % lower
