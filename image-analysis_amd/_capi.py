@@ -390,11 +390,15 @@ class Engine:
             infos.append(inf)
         return res, np.concatenate(infos)
 
-    def profiles(self, images: np.ndarray, rois: np.ndarray, inverse=False, rng=15, luts=None, roi_lut=None):
+    def profiles(self, images: np.ndarray, rois: np.ndarray, inverse=False, rng=15, luts=None, roi_lut=None, strict=True):
         """Row-mean profiles + peaks of arbitrary ROIs (ROI_DT array) over a batch resident in one upload.
 
         luts: optional (n_luts, 256) uint8 / (n_luts, 65536) uint16 point-operation tables (`point_op_lut`), applied to
-        every pixel before the row mean; roi_lut: table index per ROI (default: table 0)."""
+        every pixel before the row mean; roi_lut: table index per ROI (default: table 0).
+
+        strict (default): a ROI outside its image, an inverted ROI or a table index out of range raises ValueError before
+        anything is launched.  strict=False hands them to the device as they are: the C ABI marks each bad ROI with
+        n_peaks = -1 (include/lfa.h), its profile comes back empty, the other ROIs are unaffected."""
         images, n, H, W, Cc, code = self._prep(images)
         if n > self.max_batch:
             raise ValueError("batch larger than the engine's max_batch")
@@ -404,7 +408,7 @@ class Engine:
             return [], np.zeros(0, PEAKS_DT)
         bad = ((rois["image"] < 0) | (rois["image"] >= n) | (rois["r0"] < 0) | (rois["c0"] < 0) | (rois["r1"] > H) |
                (rois["c1"] > W * Cc) | (rois["r1"] < rois["r0"]) | (rois["c1"] < rois["c0"]))
-        if bad.any():
+        if strict and bad.any():
             raise ValueError(f"ROI {int(np.flatnonzero(bad)[0])} lies outside its image or is inverted: {rois[bad][0]}")
         stride = max(1, int((rois["r1"] - rois["r0"]).max()))
         t = to_device(images, self.device)
@@ -422,15 +426,15 @@ class Engine:
                 roi_lut = np.ascontiguousarray(roi_lut, dtype=np.int32)
                 if roi_lut.shape != (n_rois,):
                     raise ValueError("roi_lut needs one table index per ROI")
-                if ((roi_lut < 0) | (roi_lut >= n_luts)).any():
+                if strict and ((roi_lut < 0) | (roi_lut >= n_luts)).any():
                     raise ValueError(f"roi_lut holds a table index outside [0, {n_luts})")
                 rlt = to_device(roi_lut, self.device)
         profiles, peaks = self.profile_raw(t, code, n, H, W, Cc, rt, n_rois, inverse, rng, stride, lt, n_luts, rlt)
         pk = from_device(peaks, PEAKS_DT, n_rois)
-        if (pk["n_peaks"] < 0).any():                      # the kernel's own bad-ROI mark (lfa.h): no profile was written
+        if strict and (pk["n_peaks"] < 0).any():           # the kernel's own bad-ROI mark (lfa.h): no profile was written
             raise LfaError(-1, f"ROI {int(np.flatnonzero(pk['n_peaks'] < 0)[0])} was rejected by the device")
         pr = profiles.cpu().numpy().reshape(n_rois, stride)
-        return [pr[i, :max(0, pk[i]["length"])].copy() for i in range(n_rois)], pk.copy()
+        return [pr[i, :(max(0, pk[i]["length"]) if pk[i]["n_peaks"] >= 0 else 0)].copy() for i in range(n_rois)], pk.copy()
 
     def peaks(self, profiles_list, inverse=False, window_size=25, two_peaks=False, rng=15):
         n = len(profiles_list)

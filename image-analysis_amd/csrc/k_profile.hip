@@ -5,6 +5,8 @@
 // integer images this path handles that is an exact integer row sum and one float64 division.  The peak logic is the
 // shared sequential code of lfa_algo.h (bit-for-bit numpy summation order) run by a group of 16 or 64 lanes with a
 // group-parallel first-extremum search.
+#include <cstdlib>
+
 #include "lfa_internal.h"
 #include "lfa_algo.h"
 #include "lfa_device.h"
@@ -123,8 +125,9 @@ template <int G, bool LUT>
 __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int n_rois, const int32_t* counts, int slots,
                                                  const int32_t* rs_off, int inverse, int rng, double* profiles, int stride,
                                                  LfaPeaks* peaks, int lstride, const uint8_t* luts, const int32_t* roi_lut,
-                                                 int n_luts) {
+                                                 int n_luts, const int32_t* skip_if_sorted) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (skip_if_sorted && skip_if_sorted[0] == 1) return;        // k_profile_band has done the profiles (launch_profiles)
     const int rpb = blockDim.x / G;                              // ROIs per block
     const int slot = threadIdx.x / G, lg = threadIdx.x & (G - 1);
     double* sp = (double*)smem + (int64_t)slot * lstride;
@@ -264,6 +267,116 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
     if (bad && lg == 0) store_bad(&peaks[ri], len);               // k_peaks skips ROIs it finds bad by the same test
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Dense ROI sets (BASELINE configs[4]: hundreds of ROIs per image, together covering the image about once, overlapping):
+// one block owns a band of RB rows of one image and serves EVERY ROI that crosses the band, so each image byte is
+// fetched once per band -- coalesced, whole rows, staged in LDS -- instead of once per ROI in 48..192-byte row pieces
+// (k_profile above: 1.6x line over-fetch and every overlap fetched again).  Needs the ROI array sorted by image
+// (k_roi_index checks that and writes the first ROI of every image); a band crossed by few ROI rows skips the staging and
+// reads the row pieces from global memory.  profile[r] = exact integer row sum / element count, one (ROI, row) per
+// 16-lane group, so no accumulation order and no atomics are involved.
+// ---------------------------------------------------------------------------------------------------------------
+
+// One block.  idx[0] = 1 iff rois[].image is non-decreasing; idx[1 + k] = first ROI with image >= k, k = 0..n.
+__global__ __launch_bounds__(1024) void k_roi_index(const LfaRoi* rois, int n_rois, int n_images, int32_t* idx) {
+    int unsorted = 0;
+    for (int i = threadIdx.x; i < n_rois; i += blockDim.x) {
+        const int cur = rois[i].image;
+        const int prev = i ? rois[i - 1].image : -1;
+        if (cur < prev) unsorted = 1;
+        // images (prev, cur] start at i (clipped to the images there are)
+        int lo = prev + 1 < 0 ? 0 : prev + 1, hi = cur < n_images ? cur : n_images;
+        for (int k = lo; k <= hi; ++k) idx[1 + k] = i;
+    }
+    const int last = n_rois ? rois[n_rois - 1].image : -1;
+    for (int k = (last + 1 < 0 ? 0 : last + 1) + threadIdx.x; k <= n_images; k += blockDim.x) idx[1 + k] = n_rois;
+    unsorted = __syncthreads_or(unsorted);
+    if (threadIdx.x == 0) idx[0] = unsorted ? 0 : 1;
+}
+
+// sum of the elements in bytes [b0, b0 + nbytes) of the row at `row` (16-byte aligned, LDS or global), by one lane:
+// 16-byte pieces, the first and the last masked per byte
+template <class PTR>
+__device__ __forceinline__ uint32_t lane_row_sum(PTR row, int b0, int nbytes, int esz) {
+    const int a0 = b0 & ~15;
+    const int nch = (((b0 + nbytes + 15) & ~15) - a0) >> 4;
+    uint32_t sv = 0u;
+    for (int d = 0; d < nch; ++d) {
+        const uint4 x = *(const uint4*)(row + a0 + 16 * d);
+        uint32_t w[4] = {x.x, x.y, x.z, x.w};
+        if (d == 0 || d == nch - 1) {
+            const int lo = b0 - (a0 + 16 * d), hi = b0 + nbytes - (a0 + 16 * d);   // keep bytes [lo, hi) of the piece
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int l = min(max(lo - 4 * k, 0), 4), h = min(max(hi - 4 * k, 0), 4);
+                w[k] &= (l >= 4 ? 0u : (0xffffffffu << (8 * l))) & (h >= 4 ? 0xffffffffu : ~(0xffffffffu << (8 * h)));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sv = (esz == 1) ? __builtin_amdgcn_sad_u8(w[k], 0u, sv) : (sv + (w[k] & 0xffffu) + (w[k] >> 16));
+    }
+    return sv;
+}
+
+constexpr int kBandList = 512;         // ROIs of one image handled per round of a band block
+constexpr int kBandRegs = 6;           // 16-byte pieces of the band a thread holds in registers on the way to LDS (24 KiB per block)
+
+// RBL = log2(rows per band); the band (<= 256 * kBandRegs * 16 bytes) is requested before anything else and lands in LDS
+// while the block looks up its image's ROIs
+__global__ __launch_bounds__(256) void k_profile_band(Job j, const LfaRoi* rois, const int32_t* idx, int RBL, int stride,
+                                                      double* profiles) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int4 s_box[kBandList];                            // r0, r1, first byte and byte count of a row of the window
+    __shared__ int s_roi[kBandList];
+    __shared__ int s_n;
+    const int tid = threadIdx.x;
+    const int image = blockIdx.y;
+    const int RB = 1 << RBL;
+    const int y0 = blockIdx.x << RBL, y1 = min(y0 + RB, j.H);
+    const int esz = (j.dtype == LFA_U16) ? 2 : 1;
+    const int row_bytes = j.W * j.C * esz;
+    const uint8_t* img = j.images + (int64_t)image * j.img_bytes;
+    const int n16 = ((y1 - y0) * row_bytes) >> 4;
+    const uint4* src = (const uint4*)(img + (int64_t)y0 * row_bytes);
+    uint4 hold[kBandRegs];
+#pragma unroll
+    for (int u = 0; u < kBandRegs; ++u) hold[u] = (tid + 256 * u < n16) ? src[tid + 256 * u] : make_uint4(0u, 0u, 0u, 0u);
+    const int sorted = idx[0];
+    const int first = idx[1 + image], end = idx[2 + image];
+    if (sorted != 1) return;                                     // unsorted ROI array: k_profile runs instead
+    bool staged = false;
+    for (int base = first; base < end; base += kBandList) {
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        const int lim = min(end, base + kBandList);
+        for (int i = base + tid; i < lim; i += blockDim.x) {
+            const LfaRoi r = rois[i];
+            const int len = r.r1 - r.r0;
+            const bool bad = r.r0 < 0 || r.r1 > j.H || r.c0 < 0 || r.c1 > j.W || len < 0 || r.c1 < r.c0 || len > stride;
+            if (!bad && r.image == image && r.r0 < y1 && r.r1 > y0) {
+                const int k = atomicAdd(&s_n, 1);
+                s_roi[k] = i;
+                s_box[k] = make_int4(r.r0, r.r1, r.c0 * j.C * esz, (r.c1 - r.c0) * j.C * esz);
+            }
+        }
+        if (!staged) {
+#pragma unroll
+            for (int u = 0; u < kBandRegs; ++u) if (tid + 256 * u < n16) ((uint4*)smem)[tid + 256 * u] = hold[u];
+            staged = true;
+        }
+        __syncthreads();
+        const int nl = s_n;
+        for (int it = tid; it < (nl << RBL); it += blockDim.x) {  // one (ROI, row) per lane
+            const int q = it >> RBL, y = y0 + (it & (RB - 1));
+            const int4 bx = s_box[q];
+            if (y < bx.x || y >= bx.y) continue;
+            const uint32_t sv = lane_row_sum((const unsigned char*)smem + (y - y0) * row_bytes, bx.z, bx.w, esz);
+            profiles[(int64_t)s_roi[q] * stride + (y - bx.x)] = (double)sv / (double)(bx.w / esz);
+        }
+        __syncthreads();
+    }
+}
+
 // numpy's pairwise sum (lfa_algo.h np_pairwise) with the eight running sums of a leaf spread over eight lanes: lane j adds
 // the terms j, j+8, j+16, ... in that order -- exactly the chain numpy's r[j] follows -- then the eight partial sums are
 // exchanged and combined as numpy combines them.
@@ -392,8 +505,27 @@ static void launch_peaks_k(const double* profiles, const int32_t* lengths, int n
 
 hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const int32_t* counts, int slots,
                            const int32_t* rs_off, int inverse, int rng, double* profiles, int stride, LfaPeaks* peaks,
-                           const uint8_t* luts, int n_luts, const int32_t* roi_lut, hipStream_t s) {
+                           const uint8_t* luts, int n_luts, const int32_t* roi_lut, hipStream_t s, int32_t* roi_idx) {
     if (n_rois <= 0) return hipSuccess;
+    // dense ROI sets take the band kernel (see k_profile_band): plain profiles of aligned images with rows that fit the LDS
+    // band, at least 32 ROIs per image on average, a ROI array sorted by image (checked on the device: k_roi_index; an
+    // unsorted array makes the band kernel return at once and k_profile, launched behind it with the opposite test, run)
+    const int64_t row_bytes = (int64_t)j.W * j.C * (j.dtype == LFA_U16 ? 2 : 1);
+    int band_rows = 0;
+    if (roi_idx && !luts && !counts && j.aligned16 && (row_bytes & 15) == 0 && row_bytes <= 256 * kBandRegs * 16 && (int64_t)n_rois >= 32ll * j.n) {
+        static const int band_kb = [] { const char* e = getenv("LFA_BAND_KB"); return e ? atoi(e) : 24; }();
+        int rbl = 3;                                             // rows per band: 8, 4, 2 or 1 -- the band must fit its registers / LDS
+        while (rbl > 0 && (((int64_t)row_bytes << rbl) > (int64_t)band_kb * 1024 || ((int64_t)row_bytes << rbl) > 256 * kBandRegs * 16)) --rbl;
+        band_rows = 1 << rbl;
+    }
+    if (band_rows) {
+        int rbl = 0;
+        while ((1 << rbl) < band_rows) ++rbl;
+        LFA_LAUNCH("k_roi_index", k_roi_index, dim3(1), dim3(1024), 0, s, rois, n_rois, j.n, roi_idx);
+        const dim3 grid((j.H + band_rows - 1) / band_rows, j.n);
+        LFA_LAUNCH("k_profile_band", k_profile_band, grid, dim3(256), (size_t)band_rows * row_bytes, s, j, rois, roi_idx, rbl, stride,
+                   profiles);
+    }
     // the analyze path only ever profiles windows of int(.6h) - int(.25h) <= 0.35*H + 1 rows: size the LDS for that
     int max_len = stride;
     if (counts) {
@@ -412,10 +544,10 @@ hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const i
         const size_t acc_bytes = (size_t)waves * lstride * 8;
         if (luts)
             LFA_LAUNCH("k_profile_lut", (k_profile<64, true>), grid, block, acc_bytes + (size_t)waves * 256, s, j, rois, n_rois, counts,
-                       slots, rs_off, inverse, rng, profiles, stride, peaks, lstride, luts, roi_lut, n_luts);
+                       slots, rs_off, inverse, rng, profiles, stride, peaks, lstride, luts, roi_lut, n_luts, nullptr);
         else
             LFA_LAUNCH("k_profile", (k_profile<64, false>), grid, block, acc_bytes, s, j, rois, n_rois, counts, slots, rs_off,
-                       inverse, rng, profiles, stride, peaks, lstride, luts, roi_lut, n_luts);
+                       inverse, rng, profiles, stride, peaks, lstride, luts, roi_lut, n_luts, band_rows ? roi_idx : nullptr);
     }
     // peaks: the sequential search, 16 lanes per profile
     launch_peaks_k(profiles, nullptr, n_rois, stride, max_len, inverse, 25, 1, rng, peaks, j, rois, counts, slots,

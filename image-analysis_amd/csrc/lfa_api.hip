@@ -134,6 +134,7 @@ struct LfaContext {
     int debug_flags = 0;
     Workspace ws;
     Buf lut8, lut16;
+    Buf roi_idx;                           // max_batch + 2 words: ROI array index of lfa_profile_batch's band kernel
     hipEvent_t done_event = nullptr;       // end of the handle's most recent detect/analyze call (orders calls across streams)
     hipStream_t last_stream = nullptr;
     bool have_done = false;
@@ -161,7 +162,7 @@ struct LfaContext {
     int win_hint = 0;                      // longest analysis window of the last completed call (rows), 0 = unknown
     std::vector<Buf*> all() {
         std::vector<Buf*> v = ws.all();
-        v.push_back(&lut8); v.push_back(&lut16); v.push_back(&plane_stats);
+        v.push_back(&lut8); v.push_back(&lut16); v.push_back(&plane_stats); v.push_back(&roi_idx);
         return v;
     }
 };
@@ -459,6 +460,7 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         return fail(LFA_ERR_HIP, "hipEventCreate failed");
     }
     if ((rc = ensure(h->plane_stats, lfa::kStatsWords * 4))) { lfa_destroy(h); return rc; }
+    if ((rc = ensure(h->roi_idx, ((size_t)max_batch + 2) * 4))) { lfa_destroy(h); return rc; }
     if (hipHostMalloc((void**)&h->plane_host, lfa::kStatsWords * 4, hipHostMallocDefault) != hipSuccess) {
         h->plane_host = nullptr; lfa_destroy(h);
         return fail(LFA_ERR_NOMEM, "hipHostMalloc failed");
@@ -550,10 +552,14 @@ static int profile_impl(LfaHandle h, const void* images, int dtype, int n, int H
     j.img_bytes = (int64_t)H * W * C * (dtype == LFA_U16 ? 2 : 1);
     j.n = n; j.H = H; j.W = W; j.C = C; j.dtype = dtype;
     j.aligned16 = (((uintptr_t)images & 15) == 0 && (j.img_bytes & 15) == 0) ? 1 : 0;
+    // the band kernel's ROI index lives in the handle: ordered with the handle's other calls like the detect workspace
+    if (h->have_done && (hipStream_t)stream != h->last_stream) LFA_HIP(hipStreamWaitEvent((hipStream_t)stream, h->done_event, 0));
     TimerScope ts(h);
     LFA_HIP(lfa::launch_profiles(j, rois, n_rois, nullptr, 0, nullptr, inverse, range, out_profiles, profile_stride, out_peaks,
                                  with_lut ? (const uint8_t*)luts : nullptr, n_luts, with_lut ? roi_lut : nullptr,
-                                 (hipStream_t)stream));
+                                 (hipStream_t)stream, (int32_t*)h->roi_idx.p));
+    LFA_HIP(hipEventRecord(h->done_event, (hipStream_t)stream));
+    h->last_stream = (hipStream_t)stream; h->have_done = true;
     return LFA_OK;
 }
 

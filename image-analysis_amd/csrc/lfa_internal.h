@@ -121,7 +121,7 @@ hipError_t launch_regions(const Job& j, const OutPtrs& o, hipStream_t s); // can
 hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const int32_t* counts_or_null,
                            int max_strips_or_0, const int32_t* rs_off_or_null, int inverse, int rng, double* profiles,
                            int stride, LfaPeaks* peaks, const uint8_t* luts_or_null, int n_luts, const int32_t* roi_lut_or_null,
-                           hipStream_t s);
+                           hipStream_t s, int32_t* roi_idx_or_null = nullptr);   // roi_idx: n + 2 words of scratch -> band kernel allowed
 hipError_t launch_peaks(const double* profiles, const int32_t* lengths, int n, int stride, int inverse, int window,
                         int two, int rng, LfaPeaks* out, hipStream_t s);
 hipError_t launch_gaussian_w(const Job& j, const double* w, int radius, void* out, int out_f32, hipStream_t s);

@@ -358,7 +358,10 @@ def test_profile_tables_per_roi_batch(dtype):
         # a table index out of range marks that ROI, and only that ROI, as bad
         which_bad = which.copy()
         which_bad[1] = len(params)
-        _p, pk2 = eng.profiles(batch, rois, luts=luts, roi_lut=which_bad)
+        with pytest.raises(ValueError):
+            eng.profiles(batch, rois, luts=luts, roi_lut=which_bad)
+        _p, pk2 = eng.profiles(batch, rois, luts=luts, roi_lut=which_bad, strict=False)
+        assert len(_p[1]) == 0 and len(_p[0]) == pk[0]["length"]
         assert pk2[1]["n_peaks"] == -1 and pk2[0]["n_peaks"] == pk[0]["n_peaks"] and pk2[2]["area"][0] == pk[2]["area"][0]
         eng.close()
 
@@ -404,3 +407,52 @@ def test_random_profiles_peak_logic_against_oracle(seed):
                     for q, (s, e, a) in enumerate(want):
                         assert (int(pk[i]["start"][q]), int(pk[i]["end"][q])) == (s, e), (seed, i, inverse, r, q)
                         assert pk[i]["area"][q] == a, (seed, i, inverse, r, q)
+
+
+@pytest.mark.parametrize("kind", ["rgb", "u16", "u8"])
+def test_dense_rois_take_the_band_kernel_and_match_the_oracle(kind):
+    """lfa_profile_batch with many ROIs per image (configs[4]): ROI array sorted by image -> k_profile_band (row bands staged
+    in LDS, every ROI crossing a band served from it); the same ROIs shuffled -> the per-ROI kernel.  Both must equal the
+    oracle bit for bit; degenerate ROIs (no rows, no columns) included."""
+    import image_analysis_amd._capi as capi
+    from image_analysis_amd.synth import synth_rgb, synth_rois, synth_u16
+    if kind == "rgb":
+        imgs = np.stack([synth_rgb(200, 256, 4, 70 + i) for i in range(3)])
+    elif kind == "u16":
+        imgs = np.stack([synth_u16(200, 256, 6, 70 + i) for i in range(3)])
+    else:
+        imgs = np.stack([synth_rgb(200, 256, 4, 70 + i)[:, :, 0].copy() for i in range(3)])
+    n, H, W = imgs.shape[:3]
+    rng = np.random.default_rng(8)
+    rois = np.zeros(n * 48, dtype=capi.ROI_DT)
+    rois["image"] = np.repeat(np.arange(n), 48)
+    h = rng.integers(1, 150, size=len(rois)); w = rng.integers(1, 64, size=len(rois))
+    rois["r0"] = (rng.random(len(rois)) * (H - h)).astype(int); rois["r1"] = rois["r0"] + h
+    rois["c0"] = (rng.random(len(rois)) * (W - w)).astype(int); rois["c1"] = rois["c0"] + w
+    rois["r1"][5] = rois["r0"][5]                              # no rows: empty profile
+    rois["c1"][7] = rois["c0"][7]                              # no columns: NaN profile (np.nanmean of an empty slice)
+    rois[9] = (1, 0, H, 0, W)                                  # the whole image
+    rois = rois[np.argsort(rois["image"], kind="stable")]
+    eng = capi.Engine(device=0, max_h=H, max_w=W, max_batch=n)
+    try:
+        for order in (np.arange(len(rois)), rng.permutation(len(rois))):
+            rr = rois[order]
+            eng.timing("*")
+            profs, pk = eng.profiles(imgs, rr, inverse=False, rng=15)
+            kt = eng.timing_read()
+            eng.timing(None)
+            assert "k_profile_band" in kt and "k_roi_index" in kt
+            for q, r in enumerate(rr):
+                reg = imgs[r["image"], r["r0"]:r["r1"], r["c0"]:r["c1"]]
+                if reg.shape[0] == 0:
+                    assert len(profs[q]) == 0 and pk[q]["n_peaks"] == 0
+                    continue
+                wp, wk = O.image_analysis(reg, True)
+                assert np.array_equal(profs[q], wp, equal_nan=True), q
+                if reg.shape[1] == 0:
+                    continue
+                assert pk[q]["n_peaks"] == len(wk), q
+                for i, (s, e, a) in enumerate(wk):
+                    assert (pk[q]["start"][i], pk[q]["end"][i]) == (s, e) and pk[q]["area"][i] == a, q
+    finally:
+        eng.close()
