@@ -673,6 +673,7 @@ int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H,
     j.images = (const uint8_t*)images;
     j.img_bytes = (int64_t)H * W * C * (dtype == LFA_U16 ? 2 : 1);
     j.n = n; j.H = H; j.W = W; j.C = C; j.dtype = dtype;
+    j.aligned16 = (((uintptr_t)images & 15) == 0 && (j.img_bytes & 15) == 0) ? 1 : 0;
     TimerScope ts(h);
     LFA_HIP(lfa::launch_gaussian_w(j, w, radius, out, out_f32, (hipStream_t)stream));
     return LFA_OK;

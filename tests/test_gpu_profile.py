@@ -456,3 +456,24 @@ def test_dense_rois_take_the_band_kernel_and_match_the_oracle(kind):
                     assert (pk[q]["start"][i], pk[q]["end"][i]) == (s, e) and pk[q]["area"][i] == a, q
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("shape,dtype", [((64, 256, 3), np.uint8), ((37, 1000, 3), np.uint8), ((50, 352), np.uint8), ((130, 100), np.uint16),
+                                          ((40, 2048), np.uint16), ((33, 97, 3), np.uint8), ((5, 7), np.uint8)])
+@pytest.mark.parametrize("sigma", [1.0, 2.0, 0.5])
+def test_gaussian_float32_output(shape, dtype, sigma):
+    """out_f32 (no counterpart in the reference, which returns float64): float32 arithmetic on the vector path (rows of a
+    multiple of 4 elements), the float64 kernel with a rounded store otherwise; either way within 1e-6 of the float64
+    result, on values in [0, 1] (stated tolerance of the float32 variant: atol 1e-6)."""
+    import image_analysis_amd._capi as capi
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, np.iinfo(dtype).max + 1, size=shape).astype(dtype)
+    eng = capi.Engine(device=0, max_h=shape[0], max_w=shape[1], max_batch=2)
+    try:
+        got = eng.gaussian(np.stack([img, img[::-1].copy()]), sigma=sigma, out_f32=True)
+        assert got.dtype == np.float32
+        for k, im in enumerate((img, img[::-1])):
+            want = O.gaussian(im, sigma)
+            np.testing.assert_allclose(got[k].astype(np.float64), want, rtol=0, atol=1e-6)
+    finally:
+        eng.close()
