@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblfa_hip.so")
+LIB_PATH = os.environ.get("LFA_LIB_PATH") or os.path.join(_HERE, "liblfa_hip.so")     # LFA_LIB_PATH: an experimental build (tools/)
 
 LFA_U8, LFA_U16 = 0, 1
 DBG_MASK, DBG_OPENED, DBG_LABELS, DBG_TABLE, DBG_HIST, DBG_PLANE, DBG_ONEPASS = 0, 1, 2, 3, 4, 5, 6

@@ -325,17 +325,22 @@ __global__ void k_zero_hist_u16(Job j) {
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nb; k += gridDim.x * blockDim.x) gh[k] = 0;
 }
 
+#ifndef LFA_HIST_COPIES
+#define LFA_HIST_COPIES 16
+#endif
+constexpr int kHC = LFA_HIST_COPIES;
+
 template <int V>
 __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     // 16 sub-histograms: lane l adds into copy l & 15, i.e. word (bin << 4) | (l & 15); the 16 lanes with different copies
     // sit on 16 different banks, two lanes with the same copy collide only when their bins have the same parity
-    __shared__ uint32_t sh[256 * 16];
+    __shared__ uint32_t sh[256 * kHC];
     __shared__ double st[kEdges + 1];
     const int img = blockIdx.y;
     if (j.info[img].all_equal) return;
-    for (int k = threadIdx.x; k < 256 * 16; k += 256) sh[k] = 0;
-    uint32_t* shl = sh + (threadIdx.x & 15);
-    auto hadd = [&](uint32_t k) { atomicAdd(&shl[k << 4], 1u); };
+    for (int k = threadIdx.x; k < 256 * kHC; k += 256) sh[k] = 0;
+    uint32_t* shl = sh + (threadIdx.x & (kHC - 1));
+    auto hadd = [&](uint32_t k) { atomicAdd(&shl[k * kHC], 1u); };
     const double* te = j.edges_g + (int64_t)img * kEdges;
     for (int k = threadIdx.x; k < kEdges; k += 256) st[k] = te[k];
     __syncthreads();
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     __syncthreads();
     uint32_t tot = 0;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) tot += sh[(threadIdx.x << 4) + ((c + threadIdx.x) & 15)];     // rotated: spreads the lanes over the banks
+    for (int c = 0; c < kHC; ++c) tot += sh[threadIdx.x * kHC + ((c + threadIdx.x) & (kHC - 1))];     // rotated: spreads the lanes over the banks
     if (tot) atomicAdd(&j.hist[(int64_t)img * j.hist_stride + threadIdx.x], tot);
     amb = wave_sum_u32(amb);
     if ((threadIdx.x & 63) == 0 && amb) atomicAdd(&j.info[img].ambiguous, amb);
