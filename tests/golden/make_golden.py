@@ -61,6 +61,10 @@ def excel2():
     crop_png = z.read("xl/media/image2.png")
     open(os.path.join(HERE, "excel2_frame.png"), "wb").write(frame_png)
     open(os.path.join(HERE, "excel2_crop.png"), "wb").write(crop_png)
+    # the worksheet and drawing parts of the same workbook, as data: what the reference's export writes for this profile and
+    # these pictures (image_analysis_amd.export.write_profile_xlsx must reproduce them byte for byte)
+    open(os.path.join(HERE, "excel2_sheet1.xml"), "wb").write(z.read("xl/worksheets/sheet1.xml"))
+    open(os.path.join(HERE, "excel2_drawing1.xml"), "wb").write(z.read("xl/drawings/drawing1.xml"))
     sheet = z.read("xl/worksheets/sheet1.xml").decode()
     vals = [float(v) for v in re.findall(r'<c r="B\d+"><v>([^<]+)</v>', sheet)]
     frame = np.array(Image.open(io.BytesIO(frame_png)))

@@ -3,6 +3,8 @@
 CPU part: imread / iter_tiff_pages on files written here with PIL (lossless: TIFF, PNG), shapes, dtypes and channel
 order as detection.py:454 would deliver them.  GPU part: analyze_stream == the oracle frame by frame, in order, across
 batch boundaries."""
+import os
+
 import numpy as np
 import pytest
 from PIL import Image
@@ -125,3 +127,31 @@ def test_batch_csv_tables(tmp_path):
     assert len(pr) == 1 + 4 and pr[3] == ["7", "0", "2", repr(1 / 3)]
     assert su[1][:8] == ["7", "0", "1", "11", "3", "8", "50", "2"] and float(su[1][13]) == 2.5
     assert su[2][7] == "1" and su[2][11:] == ["", "", ""] and float(su[2][10]) == 1 / 3
+
+
+def test_profile_xlsx_is_the_reference_workbook(tmp_path, golden_dir):
+    """export.write_profile_xlsx against the reference's own export images/excel2.xlsx (download_data, detection.py:735-759):
+    for the same profile and pictures of the same sizes, the worksheet part and the drawing part are byte-identical to the
+    reference's (tests/golden/excel2_sheet1.xml, excel2_drawing1.xml, copied out of that workbook), and the file reads back."""
+    import zipfile
+    from image_analysis_amd import export as E
+    ka = np.load(os.path.join(golden_dir, "excel2_known_answer.npz"))
+    prof = ka["profile_column_B"]
+    frame_png = open(os.path.join(golden_dir, "excel2_frame.png"), "rb").read()
+    crop = np.array(Image.open(os.path.join(golden_dir, "excel2_crop.png")))
+    plot = np.zeros((600, 600, 4), np.uint8)                      # the GUI's matplotlib canvas is 600 x 600 RGBA
+    p = str(tmp_path / "out.xlsx")
+    E.write_profile_xlsx(p, prof, images=[frame_png, crop, plot])
+    with zipfile.ZipFile(p) as z:
+        assert z.testzip() is None
+        assert z.read("xl/worksheets/sheet1.xml") == open(os.path.join(golden_dir, "excel2_sheet1.xml"), "rb").read()
+        assert z.read("xl/drawings/drawing1.xml") == open(os.path.join(golden_dir, "excel2_drawing1.xml"), "rb").read()
+        assert z.read("xl/media/image1.png") == frame_png
+        assert np.array_equal(np.array(Image.open(__import__("io").BytesIO(z.read("xl/media/image2.png")))), crop)
+    assert np.array_equal(E.read_profile_xlsx(p), prof)
+    # a value that %.16G would not bring back keeps its last bit; no pictures -> no drawing part
+    odd = np.array([0.1 + 0.2, 1 / 3, 120.30000000000001, 5e-324, 1e300])
+    E.write_profile_xlsx(p, odd)
+    assert np.array_equal(E.read_profile_xlsx(p), odd)
+    with zipfile.ZipFile(p) as z:
+        assert "xl/drawings/drawing1.xml" not in z.namelist()
