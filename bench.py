@@ -16,9 +16,11 @@ collective backend (RCCL; `shard.gather_strip_records`), as north_star's "final 
 One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel of the step (found in warm-up with every
 kernel timed, then timed alone with HIP events inside the timed region); its algorithmic bytes are the image bytes one
 launch reads plus what it must write.  `cpu_baseline` is the oracle (numpy/scipy restatement of the reference
-arithmetic) on a bounded sample of the same images on the host.  `configs` holds the other BASELINE.json configurations,
-measured after the headline region in the same process: configs[3] (3072x4096 images; at every N, with its own record
-gather) and, at N = 1, configs[2], the reference's own 16-bit frame, configs[4] and the Gaussian stage.
+arithmetic) on a bounded sample of the same images on the host.  `configs` holds the other BASELINE.json configurations:
+at N = 1 configs[3] (3072x4096 images, with its own record gather), configs[2], the reference's own 16-bit frame,
+configs[4] and the Gaussian stage, measured by `benchmarks_configs.py all` in a child process that finishes before this
+one initialises the GPU; at N > 1 configs[3] on every rank (weak scaling) with its record gather over RCCL.
+`sustained_hbm` prices the whole step in HBM bytes actually moved (PMC counters per kernel, profiles/traffic.json).
 """
 import argparse
 import importlib
@@ -98,21 +100,15 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
-def strip_records(capi, strips_t, counts_np, peaks_t, max_strips, image0):
-    """The fixed-size per-strip result record of every strip of this rank: image index, box, area, label, the peaks."""
-    B = len(counts_np)
-    st = capi.from_device(strips_t, capi.STRIP_DT, B * max_strips).reshape(B, max_strips)
-    pk = capi.from_device(peaks_t, capi.PEAKS_DT, B * max_strips).reshape(B, max_strips)
-    dt = np.dtype([("image", "<i4"), ("strip", capi.STRIP_DT), ("peaks", capi.PEAKS_DT)])
-    rec = np.zeros(int(counts_np.sum()), dtype=dt)
-    k = 0
-    for i in range(B):
-        c = int(counts_np[i])
-        rec["image"][k:k + c] = image0 + i
-        rec["strip"][k:k + c] = st[i, :c]
-        rec["peaks"][k:k + c] = pk[i, :c]
-        k += c
-    return rec
+def secondary_child(args):
+    """The other configurations (benchmarks_configs.py all), in a process of their own that has the GPU to itself and has
+    finished before this process initialises the device: measured in one process after the headline batch, configs[3]
+    came out 10-14 % lower (placement of its buffers among what the headline run had held)."""
+    cmd = [sys.executable, os.path.join(ROOT, "benchmarks_configs.py"), "all", "--steps", str(args.config_steps)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise RuntimeError("secondary configurations failed: " + r.stderr[-3000:])
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
 
 def main():
@@ -132,6 +128,9 @@ def main():
     cpu = None
     if args.cpu_sample > 0 and rank == 0:
         cpu = cpu_baseline(args, pool_run=(world == 1))
+    configs = None
+    if world == 1 and not args.no_configs:
+        configs = secondary_child(args)
 
     import torch
     import torch.distributed as dist
@@ -220,7 +219,8 @@ def main():
         """every rank ends with the records of all world*n_local images in image order; returns (records, seconds)"""
         torch.cuda.synchronize()
         cn = counts_t.cpu().numpy()
-        rec = strip_records(capi, strips_t, cn, peaks_t, ms, rank * n_local)
+        rec = shard.pack_strip_records(capi.from_device(strips_t, capi.STRIP_DT, n_local * ms).reshape(n_local, ms),
+                                       capi.from_device(peaks_t, capi.PEAKS_DT, n_local * ms).reshape(n_local, ms), cn, rank * n_local)
         barrier()
         t0 = time.perf_counter()
         all_counts, all_rec = shard.gather_strip_records(cn, rec, world * n_local, device=cdev)
@@ -276,12 +276,10 @@ def main():
     del batch, profiles
     torch.cuda.empty_cache()
 
-    # ---- the other configurations, after the headline region (the `configs` object) ----
-    configs = None
-    if not args.no_configs:
+    # ---- N > 1: configs[3] (the configuration BASELINE.json names for the scaling curve) on every rank, with its own gather
+    if world > 1 and not args.no_configs:
         bc = importlib.import_module("benchmarks_configs")
-        configs = {}
-        r = bc.bench_big(steps=args.config_steps, seed0=77 + 4 * rank, keep_pipeline=True, barrier=barrier if world > 1 else None)
+        r = bc.bench_big(steps=args.config_steps, seed0=77 + 4 * rank, keep_pipeline=True, barrier=barrier)
         pl = r.pop("_pipeline")
         dt3 = max_over_ranks(r["ms_per_step"] * 1e-3)
         s3 = sum_over_ranks(r["strips_per_step"])
@@ -289,15 +287,12 @@ def main():
         assert int(c3.sum()) == s3 == len(rec3)
         pl.close()
         del pl
-        torch.cuda.empty_cache()
         r.update({"n_gpus": world, "scaling": "weak", "ms_per_step": round(dt3 * 1e3, 3),
                   "images_per_s": round(world * r["images"] / dt3, 1), "strips_per_s": round(s3 / dt3, 1), "strips_per_step": s3,
                   "e2e_frac_hbm": round(r["images"] / dt3 * 3072 * 4096 * 3 / (HBM_PEAK_GBS * 1e9), 4),
                   "gather": {"records": len(rec3), "record_bytes": rec3.dtype.itemsize, "seconds": round(g3, 5),
-                             "backend": "gloo (rehearsal)" if rehearsal else ("rccl" if world > 1 else "none (one rank)")}})
-        configs["configs[3]"] = r
-        if world == 1:
-            configs.update(bc.secondary(steps=args.config_steps))
+                             "backend": "gloo (rehearsal)" if rehearsal else "rccl"}})
+        configs = {"configs[3]": r}
 
     if rank == 0:
         value = total_strips * args.steps / dt
@@ -336,6 +331,20 @@ def main():
                 iso_ms = step_times[dominant][0] / step_times[dominant][1]
                 roof["isolated"] = {"avg_launch_ms": round(iso_ms, 4), "achieved": round(alg_bytes / (iso_ms * 1e-3) / 1e9, 1),
                                     "frac": round(alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # the whole step in HBM bytes actually moved: per-launch PMC traffic of every kernel of a chunk (profiles/traffic.json,
+        # measured at this shape and chunk size) x chunks per step / step time
+        sustained = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            suffix = f":{H}x{W}x{C}:chunk{CH}"
+            per_chunk = sum(v for k, v in tj.items() if k.endswith(suffix))
+            if per_chunk:
+                per_step = per_chunk * ((B + CH - 1) // CH)
+                gbs = per_step / (dt / args.steps) / 1e9
+                sustained = {"hbm_bytes_per_step": per_step, "GBps": round(gbs, 1), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                             "algorithmic_bytes_per_step": B * img_bytes, "traffic_over_algorithmic": round(per_step / (B * img_bytes), 3),
+                             "source": tj.get("_source", "profiles/traffic.json")}
         out = {
             "metric": "LFA strips analysed/sec (detect+profile+peaks)", "value": round(value, 1), "unit": "strips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -349,7 +358,7 @@ def main():
             "ambiguous_pixels": amb, "peaks_in_gathered_records": n_peaks,
             "gather": {"records": len(all_rec), "record_bytes": all_rec.dtype.itemsize, "seconds": round(gather_s, 5),
                        "backend": "gloo (rehearsal)" if rehearsal else ("rccl" if world > 1 else "none (one rank)")},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "sustained_hbm": sustained, "cpu_baseline": cpu,
             "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(step_times.items(), key=lambda kv: -kv[1][0])},
             "configs": configs,
         }

@@ -287,8 +287,22 @@ def bench_stream(n=1024, batch=64, pool=8):
 
 
 def secondary(steps=10):
-    """What bench.py adds to its JSON line at N = 1 besides configs[3] (about 40 s, most of it building inputs on the host)."""
+    """What bench.py adds to its JSON line at N = 1 (about 40 s, most of it building inputs on the host)."""
+    shard = importlib.import_module("image_analysis_amd.shard")
     out = {}
+    r = bench_big(steps=steps, keep_pipeline=True)
+    pl = r.pop("_pipeline")
+    cn = pl.counts.cpu().numpy()
+    t0 = time.perf_counter()
+    rec = shard.pack_strip_records(capi.from_device(pl.strips, capi.STRIP_DT, pl.B * pl.ms).reshape(pl.B, pl.ms),
+                                   capi.from_device(pl.peaks, capi.PEAKS_DT, pl.B * pl.ms).reshape(pl.B, pl.ms), cn)
+    c3, rec3 = shard.gather_strip_records(cn, rec, pl.B)
+    r.update({"n_gpus": 1, "scaling": "weak", "gather": {"records": len(rec3), "record_bytes": rec3.dtype.itemsize,
+                                                            "seconds": round(time.perf_counter() - t0, 5), "backend": "none (one rank)"}})
+    pl.close()
+    del pl
+    out["configs[3]"] = r
+    torch.cuda.empty_cache()
     out["configs[2]"] = bench_u16(steps=steps)
     torch.cuda.empty_cache()
     out["configs[2]_excel2_frame"] = bench_u16(real=True, steps=steps)
@@ -302,8 +316,12 @@ def secondary(steps=10):
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["u16", "rois", "gauss"]
+    what = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()] or ["u16", "rois", "gauss"]
+    steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 10
     torch.cuda.set_device(0)
+    if "all" in what:                                   # bench.py's child: one JSON object with every configuration
+        print(json.dumps(secondary(steps=steps)), flush=True)
+        sys.exit(0)
 
     def show(r):
         for d in (r if isinstance(r, list) else [r]):

@@ -16,6 +16,22 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, hi
 
 
+def pack_strip_records(strips: np.ndarray, peaks: np.ndarray, counts: np.ndarray, image0: int = 0) -> np.ndarray:
+    """The fixed-size per-strip result record of every strip of a block of images: global image index, the LfaStrip
+    (box, area, label) and the LfaPeaks of its profile.  strips / peaks: [n_images][max_strips] structured arrays as the C
+    ABI fills them, counts: strips per image; image0: index of the block's first image in the whole batch."""
+    dt = np.dtype([("image", "<i4"), ("strip", strips.dtype), ("peaks", peaks.dtype)])
+    rec = np.zeros(int(counts.sum()), dtype=dt)
+    k = 0
+    for i in range(len(counts)):
+        c = int(counts[i])
+        rec["image"][k:k + c] = image0 + i
+        rec["strip"][k:k + c] = strips[i, :c]
+        rec["peaks"][k:k + c] = peaks[i, :c]
+        k += c
+    return rec
+
+
 def gather_strip_records(local_counts: np.ndarray, local_records: np.ndarray, n_items: int, device=None):
     """All-gather per-image strip counts and the packed records (any structured dtype) so that every rank ends with
     the results of all n_items images in image order.  local_counts: int32 [hi-lo]; local_records: [sum(counts)]."""
