@@ -101,14 +101,18 @@ def self_launch(args):
 
 
 def secondary_child(args):
-    """The other configurations (benchmarks_configs.py all), in a process of their own that has the GPU to itself and has
-    finished before this process initialises the device: measured in one process after the headline batch, configs[3]
-    came out 10-14 % lower (placement of its buffers among what the headline run had held)."""
-    cmd = [sys.executable, os.path.join(ROOT, "benchmarks_configs.py"), "all", "--steps", str(args.config_steps)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    if r.returncode != 0:
-        raise RuntimeError("secondary configurations failed: " + r.stderr[-3000:])
-    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    """The other configurations, each in a process of its own (`benchmarks_configs.py <name> --json`) that has the GPU to
+    itself and has finished before this process initialises the device: measured in one process after another
+    configuration, configs[2] and configs[3] came out 10-15 % lower (placement of their buffers among what the earlier
+    run had held) -- alone they repeat within 1 %."""
+    out = {}
+    for name in ("big", "u16", "u16real", "rois", "gauss"):
+        cmd = [sys.executable, os.path.join(ROOT, "benchmarks_configs.py"), name, "--json", "--steps", str(args.config_steps)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError(f"secondary configuration {name} failed: " + r.stderr[-3000:])
+        out.update(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    return out
 
 
 def main():

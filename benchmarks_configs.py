@@ -218,7 +218,7 @@ def bench_rois(B=64, per=256, steps=10):
            "rois": n, "steps": steps, "ms_per_step": round(dt * 1e3, 3), "rois_per_s": round(n / dt, 1),
            "algorithmic_bytes_per_step": byts, "GBps_algorithmic": round(byts / dt / 1e9, 1),
            "e2e_frac_hbm": round(byts / dt / (HBM_PEAK_GBS * 1e9), 4),
-           "dominant": dominant(kt, lambda k: byts if k == "k_profile" else None), "kernel_ms": _kernel_table(kt)}
+           "dominant": dominant(kt, lambda k: byts if k in ("k_profile", "k_profile_band") else None), "kernel_ms": _kernel_table(kt)}
     eng.close()
     return out
 
@@ -286,10 +286,9 @@ def bench_stream(n=1024, batch=64, pool=8):
             "host_to_device_GBps": round(n * imgs[0].nbytes / dt / 1e9, 2)}
 
 
-def secondary(steps=10):
-    """What bench.py adds to its JSON line at N = 1 (about 40 s, most of it building inputs on the host)."""
+def big_with_gather(steps=10):
+    """configs[3] plus the gather of its per-strip records (one rank: the packing and the trivial gather)."""
     shard = importlib.import_module("image_analysis_amd.shard")
-    out = {}
     r = bench_big(steps=steps, keep_pipeline=True)
     pl = r.pop("_pipeline")
     cn = pl.counts.cpu().numpy()
@@ -300,27 +299,33 @@ def secondary(steps=10):
     r.update({"n_gpus": 1, "scaling": "weak", "gather": {"records": len(rec3), "record_bytes": rec3.dtype.itemsize,
                                                             "seconds": round(time.perf_counter() - t0, 5), "backend": "none (one rank)"}})
     pl.close()
-    del pl
-    out["configs[3]"] = r
-    torch.cuda.empty_cache()
-    out["configs[2]"] = bench_u16(steps=steps)
-    torch.cuda.empty_cache()
-    out["configs[2]_excel2_frame"] = bench_u16(real=True, steps=steps)
-    torch.cuda.empty_cache()
-    out["configs[4]"] = bench_rois(steps=steps)
-    torch.cuda.empty_cache()
-    g = bench_gauss(steps=steps)
-    out["gaussian_rgb_u8_f64"], out["gaussian_u16_f64"], out["gaussian_rgb_u8_f32"] = g
-    torch.cuda.empty_cache()
-    return out
+    return r
+
+
+def named(name, steps=10):
+    """{key in bench.py's `configs` object: result} of one configuration"""
+    if name == "big":
+        return {"configs[3]": big_with_gather(steps)}
+    if name == "u16":
+        return {"configs[2]": bench_u16(steps=steps)}
+    if name == "u16real":
+        return {"configs[2]_excel2_frame": bench_u16(real=True, steps=steps)}
+    if name == "rois":
+        return {"configs[4]": bench_rois(steps=steps)}
+    if name == "gauss":
+        g = bench_gauss(steps=steps)
+        return {"gaussian_rgb_u8_f64": g[0], "gaussian_u16_f64": g[1], "gaussian_rgb_u8_f32": g[2]}
+    if name == "photo":
+        return {"photo_like_1536x2048x3": bench_photo(steps=steps)}
+    raise ValueError(name)
 
 
 if __name__ == "__main__":
     what = [a for a in sys.argv[1:] if not a.startswith("--") and not a.isdigit()] or ["u16", "rois", "gauss"]
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 10
     torch.cuda.set_device(0)
-    if "all" in what:                                   # bench.py's child: one JSON object with every configuration
-        print(json.dumps(secondary(steps=steps)), flush=True)
+    if "--json" in sys.argv:                            # bench.py's child: one JSON object {key: result}
+        print(json.dumps(named(what[0], steps)), flush=True)
         sys.exit(0)
 
     def show(r):
