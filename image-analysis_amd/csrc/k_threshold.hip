@@ -10,6 +10,8 @@
 // values and pushed through the table inside the Otsu kernel; the mask is an integer compare `pixel > x_thr`.
 // Colour images: gray is float64; the 257 histogram edges (np.linspace in gamma space) are mapped back to gray space
 // on the device by bisection over the bit patterns of the doubles, so that per pixel only compares remain.
+#include <cstdlib>
+
 #include "lfa_internal.h"
 #include "lfa_algo.h"
 #include "lfa_device.h"
@@ -81,6 +83,12 @@ __global__ __launch_bounds__(256) void k_minmax_u16(Job j) {
     }
 }
 
+// Pixels with a smaller integer G = 2125*b0 + 7154*b1 + 721*b2 have a strictly smaller float64 gray (different G are
+// >= 3.9e-7 apart in gray, the rounding of any summation order is < 4e-15), so the extremes of gray lie among the pixels
+// with the extreme G.  Per 16-pixel group the integer G of every pixel is computed (two v_dot4 each) and compared with
+// the lane's running extremes; the float64 gray is evaluated only for a pixel that sets or ties one of them with a byte
+// triple not seen there before (equal G from different triples can differ in the last bits of gray: fmin / fmax decide).
+// A lane updates its extremes a handful of times over its whole share of the image, so the pass costs the integer work.
 template <int V>
 __global__ __launch_bounds__(256) void k_minmax_rgb(Job j) {
     const int img = blockIdx.y;
@@ -92,14 +100,80 @@ __global__ __launch_bounds__(256) void k_minmax_rgb(Job j) {
     int64_t done = 0;
     if (j.aligned16) {
         const int64_t ng = npix >> 4;                 // groups of 16 pixels = 48 bytes
-        for (int64_t g = tid; g < ng; g += nth) {
+        // lane-private record of the extreme it has seen (G, byte triple, float gray); wave-wide bounds Wlo / Whi (the best G
+        // any lane of the wave holds) screen the pixels: one that does not reach them cannot be an extreme of the image
+        __shared__ uint32_t stash[12 * 256];
+        uint32_t Glo = 0x7fffffffu, Ghi = 0u, tlo = 0xffffffffu, thi = 0xffffffffu;
+        uint32_t Wlo = 0x7fffffffu, Whi = 0u;
+        const int lane = threadIdx.x & 63, wv4 = threadIdx.x >> 6;
+        // Memory shape (tools/read_probe.hip): a lane that loads its own 48 bytes as three 16-byte pieces reads at 6.2 TB/s; fully
+        // coalesced 16-byte nontemporal loads over a contiguous run per block read at 7.1.  So a wave takes a round of 64 groups
+        // (3 KiB) as three coalesced loads -- lane l gets pieces l, 64 + l, 128 + l -- and turns them through its own 3 KiB of
+        // LDS into 48 contiguous bytes per lane (both sides conflict-free: 16-byte accesses at strides of 16 and 48 bytes).
+        // Block b owns a contiguous run of rounds of its image, its four waves take them in turn.
+        __shared__ lfa_u32x4 turn[4][192];
+        const int64_t rounds = (ng + 63) >> 6;
+        const int64_t per_block = (rounds + gridDim.x - 1) / gridDim.x;
+        const int64_t r_end = min(rounds, (int64_t)(blockIdx.x + 1) * per_block);
+        const lfa_u32x4* img16 = (const lfa_u32x4*)base;
+        const int64_t n16 = ng * 3;
+        auto request = [&](int64_t r, lfa_u32x4 (&q)[3]) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int64_t i = r * 192 + 64 * k + lane;
+                q[k] = __builtin_nontemporal_load(img16 + (i < n16 ? i : r * 192));      // past the image's end: the round's first piece again
+            }
+        };
+        lfa_u32x4 nx[3];                                          // (two rounds ahead measured no better: 1.54 vs 1.50 ms per 1024 images)
+        int64_t r = (int64_t)blockIdx.x * per_block + wv4;
+        if (r < r_end) request(r, nx);
+        for (; r < r_end; r += 4) {                               // wave-uniform trip count: the reductions below need every lane
+#pragma unroll
+            for (int k = 0; k < 3; ++k) turn[wv4][64 * k + lane] = nx[k];
+            if (r + 4 < r_end) request(r + 4, nx);                // the next round's bytes travel while this round computes
+            const int mine48 = (r * 64 + lane < ng) ? lane : 0;   // a lane past the end works on the round's first group again: changes nothing
             uint32_t w[12];
-            load48(base + g * 48, w);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const lfa_u32x4 v = turn[wv4][3 * mine48 + k];
+                w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+            }
+            auto pixel = [&](int k) -> uint32_t {             // bytes 3k .. 3k+2 of the group at the low end of a dword (k constant after unrolling)
+                const int i = (3 * k) >> 2, sft = (3 * k) & 3;
+                return sft == 0 ? w[i] : (sft == 1 ? (w[i] >> 8) : __builtin_amdgcn_alignbyte(w[i + 1 < 12 ? i + 1 : i], w[i], sft));
+            };
+            bool reach = false;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const double gr = gray_u8<V>(byte_of(w, 3 * k), byte_of(w, 3 * k + 1), byte_of(w, 3 * k + 2));
-                lo = fmin(lo, gr); hi = fmax(hi, gr);
+                const uint32_t Gk = gray_G_from_dword(pixel(k));  // (the dot products give the fourth byte weight 0)
+                reach |= Gk <= Wlo || Gk >= Whi;
             }
+            if (!__any(reach)) continue;                      // the usual case: nothing in the wave's 1024 pixels reaches a bound
+            // Some pixel reaches a bound: it matters only with a byte triple other than the one this lane already holds there
+            // (the same triple again -- a black or saturated area -- changes nothing).  Rare, so this part is written for few
+            // registers, not for speed (the loop above runs all the time and its occupancy is what counts): the lane's 48
+            // bytes go to LDS and the pixels are walked one by one.
+            uint32_t* mine = stash + threadIdx.x;                 // dword d of this lane at stash[d * 256 + threadIdx.x]
+#pragma unroll
+            for (int d = 0; d < 12; ++d) mine[d * 256] = w[d];
+            bool changed = false;
+#pragma unroll 1
+            for (int k = 0; k < 16; ++k) {
+                const int b0 = 3 * k;
+                const uint32_t lo32 = mine[(b0 >> 2) * 256], hi32 = mine[min((b0 >> 2) + 1, 11) * 256];
+                const uint32_t t = (uint32_t)((((uint64_t)hi32 << 32) | lo32) >> (8 * (b0 & 3))) & 0xffffffu;
+                const uint32_t Gk = gray_G_from_dword(t);
+                const bool nlo = Gk <= Wlo && Gk <= Glo && t != tlo, nhi = Gk >= Whi && Gk >= Ghi && t != thi;
+                if (nlo || nhi) {
+                    const double gr = gray_u8<V>(t & 0xffu, (t >> 8) & 0xffu, t >> 16);
+                    if (nlo) { lo = (Gk < Glo) ? gr : fmin(lo, gr); Glo = Gk; tlo = t; }
+                    if (nhi) { hi = (Gk > Ghi) ? gr : fmax(hi, gr); Ghi = Gk; thi = t; }
+                    changed = true;
+                }
+            }
+            if (!__any(changed)) continue;
+            Wlo = (uint32_t)wave_min_i32((int)Glo);               // (G <= 2 550 000 orders the same signed or unsigned; a lane that has
+            Whi = (uint32_t)wave_max_i32((int)Ghi);               //  seen nothing yet reports INT_MAX / 0)
         }
         done = ng << 4;
     }
@@ -361,6 +435,7 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     //   bit 31    a second edge lies inside the bucket as well (only for nearly black pixels, where bins are narrower
     //             than a bucket) -> that pixel walks the edge list
     __shared__ uint32_t tab[2496];
+    __shared__ lfa_u32x4 turn[4][192];
     if (integer_path) {
         for (int k = threadIdx.x; k < kEdges + 3; k += 256) sg[k] = (k < 256) ? eg[k] : kGInf;   // sentinel above bin 255
         __syncthreads();
@@ -408,17 +483,36 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
             // stands still for a memory latency; the class-plane store of a round stays in flight across the loop
             // boundary (lfa_device.h, "vector memory operations issued by hand").  The last round asks for its own
             // group again; the copy is not used.
+            // Memory shape as in k_minmax_rgb: a wave takes a round of 64 groups (3 KiB) as three fully coalesced nontemporal
+            // 16-byte loads and turns them through its own 3 KiB of LDS into 48 contiguous bytes per lane; block b owns a
+            // contiguous run of rounds of its image, its four waves take them in turn.
+            const int lane = threadIdx.x & 63, wv4 = threadIdx.x >> 6;
+            const int64_t rounds = (ng + 63) >> 6;
+            const int64_t per_block = (rounds + gridDim.x - 1) / gridDim.x;
+            const int64_t r_end = min(rounds, (int64_t)(blockIdx.x + 1) * per_block);
+            const int64_t n16 = ng * 3;
+            auto piece = [&](int64_t r, int k) -> const uint8_t* {     // past the image's end: the round's first piece again
+                const int64_t i = r * 192 + 64 * k + lane;
+                return base + (i < n16 ? i : r * 192) * 16;
+            };
             auto pass = [&](auto plane) {
                 constexpr bool kPlane = decltype(plane)::value;
                 Raw48 nx;
-                int64_t g = tid;
-                if (g >= ng) return;
-                vm_request48(base + g * 48, nx);
+                int64_t r = (int64_t)blockIdx.x * per_block + wv4;
+                if (r >= r_end) return;
+                vm_request3nt(piece(r, 0), piece(r, 1), piece(r, 2), nx);
                 vm_wait48<0>(nx);
-                for (; g < ng; g += nth) {
+                for (; r < r_end; r += 4) {
+                    turn[wv4][lane] = nx.a; turn[wv4][64 + lane] = nx.b; turn[wv4][128 + lane] = nx.c;
+                    const int64_t rn = (r + 4 < r_end) ? r + 4 : r;
+                    vm_request3nt(piece(rn, 0), piece(rn, 1), piece(rn, 2), nx);
+                    const int64_t g = r * 64 + lane;
                     uint32_t w[12];
-                    unpack48(nx, w);
-                    vm_request48(base + (g + nth < ng ? g + nth : g) * 48, nx);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const lfa_u32x4 v = turn[wv4][3 * lane + k];
+                        w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
+                    }
                     uint32_t G[16], kb[16], flags = 0;
 #pragma unroll
                     for (int k = 0; k < 16; ++k) { G[k] = gray_G16(w, k); kb[k] = binG(G[k], flags); }
@@ -426,10 +520,12 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
 #pragma unroll
                         for (int k = 0; k < 16; ++k) kb[k] = walk(G[k], kb[k]);
                     }
-                    uint32_t pk[2] = {0u, 0u};
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) { hadd(kb[k]); pk[k >> 3] |= (kb[k] >> 4) << (4 * (k & 7)); }
-                    if (kPlane) vm_store8(bins + g * 8, pk[0], pk[1]);
+                    if (g < ng) {                                     // only the image's last round has lanes past the end; every round has
+                        uint32_t pk[2] = {0u, 0u};                    // lane 0 inside, so the store below is one operation of the wave in
+#pragma unroll                                                        // every round -- the hand-counted vmcnt waits rely on that
+                        for (int k = 0; k < 16; ++k) { hadd(kb[k]); pk[k >> 3] |= (kb[k] >> 4) << (4 * (k & 7)); }
+                        if (kPlane) vm_store8(bins + g * 8, pk[0], pk[1]);
+                    }
                     vm_wait48<kPlane ? 1 : 0>(nx);                    // the requested bytes are in; this round's store may still be on its way
                 }
             };
@@ -743,7 +839,8 @@ static int blocks_per_image(const Job& j, int px_per_block) {
 hipError_t launch_threshold(const Job& j, hipStream_t s) {
     LFA_LAUNCH("k_init_info", k_init_info, dim3(j.H >= 4096 ? 8 : 2, j.n), dim3(256), 0, s, j);
     if (j.C == 3) {
-        const dim3 grid(blocks_per_image(j, 256 * 64), j.n);
+        static const int mm_bpi = [] { const char* e = getenv("LFA_MM_BPI"); return e ? atoi(e) : 0; }();
+        const dim3 grid(mm_bpi > 0 ? mm_bpi : blocks_per_image(j, 256 * 64), j.n);
         LFA_DISPATCH_V(k_minmax_rgb, grid, dim3(256), s, j);
         LFA_LAUNCH("k_edges_rgb", k_edges_rgb, dim3(j.n), dim3(256), 0, s, j);
         {

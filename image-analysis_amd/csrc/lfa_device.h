@@ -66,6 +66,13 @@ __device__ __forceinline__ void vm_request48(const uint8_t* p, Raw48& r) {      
                  "global_load_dwordx4 %2, %3, off offset:32"
                  : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c) : "v"(p));
 }
+// three 16-byte pieces at three addresses (a wave's fully coalesced loads of a 3 KiB round), read-once hint
+__device__ __forceinline__ void vm_request3nt(const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, Raw48& r) {   // 3 operations
+    asm volatile("global_load_dwordx4 %0, %3, off nt\n\t"
+                 "global_load_dwordx4 %1, %4, off nt\n\t"
+                 "global_load_dwordx4 %2, %5, off nt"
+                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c) : "v"(p0), "v"(p1), "v"(p2));
+}
 __device__ __forceinline__ void vm_store8(void* p, uint32_t lo, uint32_t hi) {                // 1 operation
     const uint2 v = make_uint2(lo, hi);
     asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
