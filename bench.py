@@ -50,8 +50,8 @@ def parse():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--cpu-sample", type=int, default=64, help="images for the one-core CPU baseline (0 = skip); the pool run takes 8x as many")
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU pool baseline (0 = min(16, cpu_count))")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams (one LfaHandle each) the chunks alternate on")
-    ap.add_argument("--stagger", type=int, default=0, help="1: a chunk's image passes start when the previous chunk's histogram pass is done")
+    ap.add_argument("--streams", type=int, default=3, help="lanes (one LfaHandle + one HIP stream each) the chunks take in turn")
+    ap.add_argument("--stagger", type=int, default=2, help="0: lanes run free; 1: a chunk's kernels start when the previous chunk's histogram pass is done (lfa_stream_wait_passes); 2: only its image passes wait (lfa_chain_passes)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary configurations (the `configs` object)")
     ap.add_argument("--config-steps", type=int, default=10, help="timed steps of each secondary configuration")
@@ -177,6 +177,9 @@ def main():
     NS = max(1, min(args.streams, (B + CH - 1) // CH))
     engs = [capi.Engine(device=dev_index, max_h=H, max_w=W, max_c=3, max_batch=CH) for _ in range(NS)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+    if NS > 1 and args.stagger == 2:                     # standing rule: lane i's image passes follow lane i-1's
+        for i in range(NS):
+            capi._check(capi.lib.lfa_chain_passes(engs[i]._h, engs[i - 1]._h))
     strips = capi.dev_bytes(B * max_strips * capi.STRIP_DT.itemsize, dev)
     counts = torch.zeros(B, dtype=torch.int32, device=dev)
     info = capi.dev_bytes(B * capi.INFO_DT.itemsize, dev)
@@ -185,12 +188,16 @@ def main():
     peaks = capi.dev_bytes(B * max_strips * capi.PEAKS_DT.itemsize, dev)
     import ctypes
 
+    lane = [0]                                           # chunks take the lanes in turn ACROSS steps too (a lane = handle + stream)
+
     def step(ns=NS):
-        for ci, b0 in enumerate(range(0, B, CH)):
+        for b0 in range(0, B, CH):
+            ci = lane[0]
+            lane[0] += 1
             nb = min(CH, B - b0)
             e = engs[ci % ns]
             stream = ctypes.c_void_p(streams[ci % ns].cuda_stream)
-            if ns > 1 and args.stagger:
+            if ns > 1 and args.stagger == 1:
                 capi._check(capi.lib.lfa_stream_wait_passes(engs[(ci - 1) % ns]._h, stream))
             capi._check(capi.lib.lfa_analyze_batch(
                 e._h, batch.data_ptr() + b0 * img_bytes, capi.LFA_U8, nb, H, W, C, mm_r, mm_c, 10,
@@ -257,6 +264,26 @@ def main():
 
     ktimes = merge_times([e.timing_read() for e in engs]) if dominant else {}
     step_times = {}
+
+    # ---- the same steps with the lanes running free (no ordering between their passes): reported beside the timed region ----
+    free = None
+    if NS > 1 and args.stagger == 2:
+        for e in engs:
+            capi._check(capi.lib.lfa_chain_passes(e._h, None))
+        for _ in range(max(1, args.warmup)):
+            step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt_free = max_over_ranks(time.perf_counter() - t1)
+        kfree = merge_times([e.timing_read() for e in engs]) if dominant else {}
+        free = {"ms_per_step": round(dt_free / args.steps * 1e3, 3), "steps": args.steps}
+        if dominant and dominant in kfree and kfree[dominant][1] > 0:
+            free["dominant_avg_launch_ms"] = round(kfree[dominant][0] / kfree[dominant][1], 4)
+        for i in range(NS):
+            capi._check(capi.lib.lfa_chain_passes(engs[i]._h, engs[i - 1]._h))
     if dominant:                                   # one more, untimed, step with every kernel bracketed: the per-kernel table
         for e in engs:
             e.timing("*")
@@ -326,9 +353,12 @@ def main():
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
-                    "note": f"timed region runs {NS} chunk streams: a launch shares the CUs with the other stream's passes and "
-                            "tail kernels, so `frac` says how much else ran beside the kernel, not how well it uses the memory "
-                            "system; `isolated` is the same kernel in one extra untimed step on a single stream; `traffic` is "
+                    "note": (f"timed region: {NS} lanes, the image passes of consecutive chunks chained (lfa_chain_passes), so a launch of "
+                             "this kernel has the chip to itself but for the tail kernels of the chunks before; "
+                             if NS > 1 and args.stagger == 2 else
+                             f"timed region: {NS} lanes running free: a launch shares the CUs with the other lanes' passes, so `frac` says "
+                             "how much else ran beside the kernel, not how well it uses the memory system; ") +
+                            "`isolated` is the same kernel in one extra untimed step on a single stream; `traffic` is "
                             "not measured in this run: it is the PMC figure (2*FETCH_SIZE + WRITE_SIZE, KiB units) of the "
                             "rocprofv3 passes named in `traffic_source`"}
             if dominant in step_times and step_times[dominant][1] > 0:
@@ -354,7 +384,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
             "config": {"workload": f"configs[1]: {B} synthetic {W}x{H} RGB uint8 images per GPU, 8 strips each, "
-                                   f"end-to-end detect+profile+peaks", "images_per_gpu": B, "chunk": CH, "streams": NS, "pool": args.pool,
+                                   f"end-to-end detect+profile+peaks", "images_per_gpu": B, "chunk": CH, "streams": NS,
+                       "schedule": {0: "lanes run free", 1: "a chunk starts after the previous chunk's histogram pass",
+                                    2: "image passes of consecutive chunks chained, tails beside them"}[args.stagger if NS > 1 else 0],
+                       "pool": args.pool,
                        "min_maxr": mm_r, "min_maxc": mm_c, "parallelism": f"images sharded over {world} GPU(s), no collective on the data path; "
                                                                            "one gather of the per-strip records after the timed region"},
             "images_per_s": round(images_s, 1), "strips_per_step": total_strips,
@@ -363,6 +396,9 @@ def main():
             "gather": {"records": len(all_rec), "record_bytes": all_rec.dtype.itemsize, "seconds": round(gather_s, 5),
                        "backend": "gloo (rehearsal)" if rehearsal else ("rccl" if world > 1 else "none (one rank)")},
             "roofline": roof, "sustained_hbm": sustained, "cpu_baseline": cpu,
+            "free_running": (dict(free, value=round(total_strips * args.steps / (free["ms_per_step"] * 1e-3 * args.steps), 1),
+                                  note="the same steps with no ordering between the lanes' passes: passes of different chunks "
+                                       "share the chip (their launches last 2-3x as long), the step is ~3 % shorter") if free else None),
             "kernel_ms_per_step": {k: round(v[0], 3) for k, v in sorted(step_times.items(), key=lambda kv: -kv[1][0])},
             "configs": configs,
         }

@@ -70,11 +70,12 @@ def _load():
     lib.lfa_debug_fetch.argtypes = [vp, i32, i32, vp, i64, vp]
     lib.lfa_sync.argtypes = [vp, vp]
     lib.lfa_stream_wait_passes.argtypes = [vp, vp]
+    lib.lfa_chain_passes.argtypes = [vp, vp]
     lib.lfa_timing_enable.argtypes = [vp, C.c_char_p]
     lib.lfa_timing_read.argtypes = [vp, i32, vp, vp, vp, vp]
     for name in ("lfa_timing_enable", "lfa_timing_read","lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant", "lfa_detect_batch",
                  "lfa_profile_batch", "lfa_profile_lut_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch",
-                 "lfa_debug_fetch", "lfa_sync", "lfa_stream_wait_passes", "lfa_analyze_batch_static", "lfa_reserve"):
+                 "lfa_debug_fetch", "lfa_sync", "lfa_stream_wait_passes", "lfa_chain_passes", "lfa_analyze_batch_static", "lfa_reserve"):
         getattr(lib, name).restype = i32
     return lib
 
@@ -85,7 +86,7 @@ EXPORTED = ("lfa_version", "lfa_last_error", "lfa_create", "lfa_destroy", "lfa_s
             "lfa_set_debug_flags",
             "lfa_detect_batch", "lfa_profile_batch", "lfa_profile_lut_batch", "lfa_peaks_batch", "lfa_analyze_batch",
             "lfa_gaussian_batch", "lfa_debug_fetch", "lfa_sync", "lfa_timing_enable", "lfa_timing_read",
-            "lfa_stream_wait_passes", "lfa_analyze_batch_static", "lfa_static_workspace_bytes", "lfa_reserve",
+            "lfa_stream_wait_passes", "lfa_chain_passes", "lfa_analyze_batch_static", "lfa_static_workspace_bytes", "lfa_reserve",
             "lfa_workspace_bytes")
 
 

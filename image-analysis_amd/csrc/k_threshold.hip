@@ -83,6 +83,97 @@ __global__ __launch_bounds__(256) void k_minmax_u16(Job j) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// colour path: histogram edges in gray space
+// ------------------------------------------------------------------------------------------------------------------
+__device__ inline double gamma_pow(double g) { return pow(g, 0.4); }
+
+// smallest double g in [gmin, gmax] with pred(g) true, where pred is monotone (false ... false true ... true);
+// +inf if pred(gmax) is false.  Bisection on the bit patterns (non-negative doubles are ordered like int64).
+// `guess` only speeds the search up (gallop outwards from it in steps of 16^k bit patterns, then bisect); any value works.
+template <class Pred>
+__device__ inline double first_true(double gmin, double gmax, double guess, const Pred& pred) {
+    if (!pred(gmax)) return __longlong_as_double(0x7ff0000000000000LL);
+    if (pred(gmin)) return gmin;
+    long long lo = __double_as_longlong(gmin), hi = __double_as_longlong(gmax);   // pred(lo) false, pred(hi) true
+    if (hi - lo > 1 && guess == guess) {
+        long long g0 = __double_as_longlong(guess < 0.0 ? 0.0 : guess);
+        g0 = g0 <= lo ? lo + 1 : (g0 >= hi ? hi - 1 : g0);
+        long long step = 16;
+        if (pred(__longlong_as_double(g0))) {
+            hi = g0;
+            while (hi - step > lo) {
+                const long long c = hi - step;
+                if (pred(__longlong_as_double(c))) { hi = c; if (step < (1LL << 56)) step <<= 4; } else { lo = c; break; }
+            }
+        } else {
+            lo = g0;
+            while (lo + step < hi) {
+                const long long c = lo + step;
+                if (!pred(__longlong_as_double(c))) { lo = c; if (step < (1LL << 56)) step <<= 4; } else { hi = c; break; }
+            }
+        }
+    }
+    while (hi - lo > 1) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if (pred(__longlong_as_double(mid))) hi = mid; else lo = mid;
+    }
+    return __longlong_as_double(hi);
+}
+
+// ---- integer form of a gray-space threshold ------------------------------------------------------------------------------
+// gray(b0,b1,b2) is within a few ulps of G / 2 550 000 with the INTEGER G = 2125*b0 + 7154*b1 + 721*b2 (0.2125, 0.7154,
+// 0.0721 scaled by 10^4, times 255).  Different G differ by >= 4e-7 relative, the float64 rounding of any of the
+// summation orders by < 4e-15, so `gray >= t` equals `G >= ceil(t * 2 550 000)` unless an integer lies within a
+// 2^-39 relative band around t * 2 550 000 -- then the threshold is "critical" and the image takes the float64 path.
+// The band also covers the 2^-40 ambiguity census, so an image on the integer path has no ambiguous pixel by construction.
+constexpr double kGScale = 2550000.0;
+constexpr uint32_t kGInf = 0xffffffffu;
+
+__device__ inline uint32_t gray_G(uint32_t p0, uint32_t p1, uint32_t p2) { return 2125u * p0 + 7154u * p1 + 721u * p2; }
+
+__device__ inline uint32_t g_threshold(double t, bool* critical) {
+    if (!(t < 1.0e300)) return kGInf;                      // unreachable edge
+    const double A = t * kGScale;
+    const double r = rint(A);
+    if (fabs(r - A) <= A * 1.8189894035458565e-12) *critical = true;     // 2^-39
+    const double c = ceil(A);
+    return c >= 4294967295.0 ? kGInf : (uint32_t)c;
+}
+
+// 256 threads = one wave per SIMD at 72 VGPRs: that is what still fits on a CU beside the other chunk stream's histogram
+// blocks, so this kernel starts at once instead of waiting for them to retire -- with 320 threads it lasted 270 us on
+// average in the pipeline, 10 us alone.  Thread 0 also takes edge 256.
+// (Computing the edges at the end of k_minmax_rgb instead, in whichever block of an image delivers its extremes last --
+// ticket by atomics, no fence -- was bit-exact and took this launch off the critical path, but the bisection then shares
+// its SIMDs with the pass's own waves: the pass grew by 48-56 us for the 12-28 us saved.  Round 2, not kept.)
+__global__ __launch_bounds__(256) void k_edges_rgb(Job j) {
+    const int img = blockIdx.x;
+    LfaImageInfo* inf = &j.info[img];
+    const double gmin = inf->gmin, gmax = inf->gmax;
+    const double vmin = gamma_pow(gmin), vmax = gamma_pow(gmax);
+    uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
+    if (threadIdx.x == 0) { inf->vmin = vmin; inf->vmax = vmax; inf->all_equal = (vmin == vmax) ? 1 : 0; }
+    bool anycrit = false;
+    for (int i = threadIdx.x; i < kEdges; i += 256) {
+        bool crit = false;
+        double* t = j.edges_g + (int64_t)img * kEdges;
+        double ti;
+        if (vmin == vmax) {
+            ti = (i == 0) ? gmin : __longlong_as_double(0x7ff0000000000000LL);
+        } else {
+            const Linspace lin(vmin, vmax, kEdges);
+            const double e = lin(i);
+            ti = first_true(gmin, gmax, pow(e, 2.5), [e](double g) { return gamma_pow(g) >= e; });
+        }
+        t[i] = ti;
+        eg[i] = (i == 0) ? 0u : g_threshold(ti, &crit);       // edge 0 (= gmin) is below every pixel
+        anycrit |= (i >= 1 && i <= 255 && crit);
+    }
+    const int any = __syncthreads_or((anycrit || (j.debug_flags & 1)) ? 1 : 0);
+    if (threadIdx.x == 0) eg[kEdgesI_Crit] = (uint32_t)any;
+}
+
 // Pixels with a smaller integer G = 2125*b0 + 7154*b1 + 721*b2 have a strictly smaller float64 gray (different G are
 // >= 3.9e-7 apart in gray, the rounding of any summation order is < 4e-15), so the extremes of gray lie among the pixels
 // with the extreme G.  Per 16-pixel group the integer G of every pixel is computed (two v_dot4 each) and compared with
@@ -192,94 +283,6 @@ __global__ __launch_bounds__(256) void k_minmax_rgb(Job j) {
         atomicMin((unsigned long long*)&j.info[img].gmin, (unsigned long long)__double_as_longlong(lo));
         atomicMax((unsigned long long*)&j.info[img].gmax, (unsigned long long)__double_as_longlong(hi));
     }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// colour path: histogram edges in gray space
-// ------------------------------------------------------------------------------------------------------------------
-__device__ inline double gamma_pow(double g) { return pow(g, 0.4); }
-
-// smallest double g in [gmin, gmax] with pred(g) true, where pred is monotone (false ... false true ... true);
-// +inf if pred(gmax) is false.  Bisection on the bit patterns (non-negative doubles are ordered like int64).
-// `guess` only speeds the search up (gallop outwards from it in steps of 16^k bit patterns, then bisect); any value works.
-template <class Pred>
-__device__ inline double first_true(double gmin, double gmax, double guess, const Pred& pred) {
-    if (!pred(gmax)) return __longlong_as_double(0x7ff0000000000000LL);
-    if (pred(gmin)) return gmin;
-    long long lo = __double_as_longlong(gmin), hi = __double_as_longlong(gmax);   // pred(lo) false, pred(hi) true
-    if (hi - lo > 1 && guess == guess) {
-        long long g0 = __double_as_longlong(guess < 0.0 ? 0.0 : guess);
-        g0 = g0 <= lo ? lo + 1 : (g0 >= hi ? hi - 1 : g0);
-        long long step = 16;
-        if (pred(__longlong_as_double(g0))) {
-            hi = g0;
-            while (hi - step > lo) {
-                const long long c = hi - step;
-                if (pred(__longlong_as_double(c))) { hi = c; if (step < (1LL << 56)) step <<= 4; } else { lo = c; break; }
-            }
-        } else {
-            lo = g0;
-            while (lo + step < hi) {
-                const long long c = lo + step;
-                if (!pred(__longlong_as_double(c))) { lo = c; if (step < (1LL << 56)) step <<= 4; } else { hi = c; break; }
-            }
-        }
-    }
-    while (hi - lo > 1) {
-        const long long mid = lo + ((hi - lo) >> 1);
-        if (pred(__longlong_as_double(mid))) hi = mid; else lo = mid;
-    }
-    return __longlong_as_double(hi);
-}
-
-// ---- integer form of a gray-space threshold ------------------------------------------------------------------------------
-// gray(b0,b1,b2) is within a few ulps of G / 2 550 000 with the INTEGER G = 2125*b0 + 7154*b1 + 721*b2 (0.2125, 0.7154,
-// 0.0721 scaled by 10^4, times 255).  Different G differ by >= 4e-7 relative, the float64 rounding of any of the
-// summation orders by < 4e-15, so `gray >= t` equals `G >= ceil(t * 2 550 000)` unless an integer lies within a
-// 2^-39 relative band around t * 2 550 000 -- then the threshold is "critical" and the image takes the float64 path.
-// The band also covers the 2^-40 ambiguity census, so an image on the integer path has no ambiguous pixel by construction.
-constexpr double kGScale = 2550000.0;
-constexpr uint32_t kGInf = 0xffffffffu;
-
-__device__ inline uint32_t gray_G(uint32_t p0, uint32_t p1, uint32_t p2) { return 2125u * p0 + 7154u * p1 + 721u * p2; }
-
-__device__ inline uint32_t g_threshold(double t, bool* critical) {
-    if (!(t < 1.0e300)) return kGInf;                      // unreachable edge
-    const double A = t * kGScale;
-    const double r = rint(A);
-    if (fabs(r - A) <= A * 1.8189894035458565e-12) *critical = true;     // 2^-39
-    const double c = ceil(A);
-    return c >= 4294967295.0 ? kGInf : (uint32_t)c;
-}
-
-// 256 threads = one wave per SIMD at 72 VGPRs: that is what still fits on a CU beside the other chunk stream's histogram
-// blocks (5 waves x 88 VGPRs per SIMD), so this kernel starts at once instead of waiting for them to retire -- with 320
-// threads it lasted 270 us on average in the pipeline, 10 us alone.  Thread 0 also takes edge 256.
-__global__ __launch_bounds__(256) void k_edges_rgb(Job j) {
-    const int img = blockIdx.x;
-    LfaImageInfo* inf = &j.info[img];
-    const double gmin = inf->gmin, gmax = inf->gmax;
-    const double vmin = gamma_pow(gmin), vmax = gamma_pow(gmax);
-    uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
-    if (threadIdx.x == 0) { inf->vmin = vmin; inf->vmax = vmax; inf->all_equal = (vmin == vmax) ? 1 : 0; }
-    bool anycrit = false;
-    for (int i = threadIdx.x; i < kEdges; i += 256) {
-        bool crit = false;
-        double* t = j.edges_g + (int64_t)img * kEdges;
-        double ti;
-        if (vmin == vmax) {
-            ti = (i == 0) ? gmin : __longlong_as_double(0x7ff0000000000000LL);
-        } else {
-            const Linspace lin(vmin, vmax, kEdges);
-            const double e = lin(i);
-            ti = first_true(gmin, gmax, pow(e, 2.5), [e](double g) { return gamma_pow(g) >= e; });
-        }
-        t[i] = ti;
-        eg[i] = (i == 0) ? 0u : g_threshold(ti, &crit);       // edge 0 (= gmin) is below every pixel
-        anycrit |= (i >= 1 && i <= 255 && crit);
-    }
-    const int any = __syncthreads_or((anycrit || (j.debug_flags & 1)) ? 1 : 0);
-    if (threadIdx.x == 0) eg[kEdgesI_Crit] = (uint32_t)any;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -430,11 +433,12 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     const uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
     const bool integer_path = eg[kEdgesI_Crit] == 0;
     __shared__ uint32_t sg[kEdges + 3];
-    // integer path: one table word per bucket of 1024 G values (G <= 2 550 000 < 2^22):
-    //   bits 0-7  bin of the bucket's first G,  bits 8-29  the next edge above it (clamped to 2^22-1 = never reached),
-    //   bit 31    a second edge lies inside the bucket as well (only for nearly black pixels, where bins are narrower
-    //             than a bucket) -> that pixel walks the edge list
-    __shared__ uint32_t tab[2496];
+    // integer path: one table entry per bucket of 1024 G values (G <= 2 550 000 < 2^22):
+    //   .x      the next edge above the bucket's first G (clamped to 2^22-1 = never reached)
+    //   .y      bits 0-7 the bin of the bucket's first G; bit 31: a second edge lies inside the bucket as well (only for
+    //           nearly black pixels, where bins are narrower than a bucket) -> that pixel walks the edge list
+    // Two words, so that neither has to be taken apart: bin = .y + (G >= .x) is a compare and an add-with-carry.
+    __shared__ uint2 tab[2496];
     __shared__ lfa_u32x4 turn[4][192];
     if (integer_path) {
         for (int k = threadIdx.x; k < kEdges + 3; k += 256) sg[k] = (k < 256) ? eg[k] : kGInf;   // sentinel above bin 255
@@ -451,16 +455,16 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
             }
             const uint32_t e1 = sg[lo + 1] < 0x3fffffu ? sg[lo + 1] : 0x3fffffu;
             const uint32_t two = (sg[lo + 2] <= G0 + 1023u) ? 0x80000000u : 0u;
-            tab[b] = (uint32_t)lo | (e1 << 8) | two;
+            tab[b] = make_uint2(e1, (uint32_t)lo | two);
         }
         __syncthreads();
     }
     auto binG = [&](uint32_t G, uint32_t& flags) -> uint32_t {   // bin unless the bucket is flagged (then a lower bound)
-        const uint32_t ent = tab[G >> 10];
-        flags |= ent;
-        return (ent & 0xffu) + ((G >= ((ent >> 8) & 0x3fffffu)) ? 1u : 0u);
+        const uint2 ent = tab[G >> 10];                       // one 8-byte LDS read
+        flags |= ent.y;
+        return ent.y + ((G >= ent.x) ? 1u : 0u);              // bit 31 rides along: no user looks above bit 7 without masking
     };
-    auto walk = [&](uint32_t G, uint32_t k) -> uint32_t { while (G >= sg[k + 1]) ++k; return k; };   // sg[256..] = inf ends it
+    auto walk = [&](uint32_t G, uint32_t k) -> uint32_t { k &= 0xffu; while (G >= sg[k + 1]) ++k; return k; };   // sg[256..] = inf ends it
     // class plane for k_mask (integer path only): bin >> 4 of every pixel, two pixels per byte (pixel 2q in the low nibble)
     uint8_t* bins = j.bins ? j.bins + (int64_t)img * (npix >> 1) : nullptr;
     auto add = [&](double g) {                             // float64 path (an edge is critical): exact compares + census
@@ -486,27 +490,28 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
             // Memory shape as in k_minmax_rgb: a wave takes a round of 64 groups (3 KiB) as three fully coalesced nontemporal
             // 16-byte loads and turns them through its own 3 KiB of LDS into 48 contiguous bytes per lane; block b owns a
             // contiguous run of rounds of its image, its four waves take them in turn.
-            const int lane = threadIdx.x & 63, wv4 = threadIdx.x >> 6;
-            const int64_t rounds = (ng + 63) >> 6;
-            const int64_t per_block = (rounds + gridDim.x - 1) / gridDim.x;
-            const int64_t r_end = min(rounds, (int64_t)(blockIdx.x + 1) * per_block);
+            const int lane = threadIdx.x & 63, wv4 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the round loop is wave-uniform)
+            // (round numbers are 32-bit -- at most 2^20 rounds per image -- and scalar, so the loop control is scalar code)
+            const int rounds = (int)((ng + 63) >> 6);
+            const int per_block = (rounds + (int)gridDim.x - 1) / (int)gridDim.x;
+            const int r_end = min(rounds, (int)(blockIdx.x + 1) * per_block);
             const int64_t n16 = ng * 3;
-            auto piece = [&](int64_t r, int k) -> const uint8_t* {     // past the image's end: the round's first piece again
-                const int64_t i = r * 192 + 64 * k + lane;
-                return base + (i < n16 ? i : r * 192) * 16;
+            auto piece = [&](int r, int k) -> const uint8_t* {         // past the image's end: the round's first piece again
+                const int64_t i = (int64_t)r * 192 + 64 * k + lane;
+                return base + (i < n16 ? i : (int64_t)r * 192) * 16;
             };
             auto pass = [&](auto plane) {
                 constexpr bool kPlane = decltype(plane)::value;
                 Raw48 nx;
-                int64_t r = (int64_t)blockIdx.x * per_block + wv4;
+                int r = (int)blockIdx.x * per_block + wv4;
                 if (r >= r_end) return;
                 vm_request3nt(piece(r, 0), piece(r, 1), piece(r, 2), nx);
                 vm_wait48<0>(nx);
                 for (; r < r_end; r += 4) {
                     turn[wv4][lane] = nx.a; turn[wv4][64 + lane] = nx.b; turn[wv4][128 + lane] = nx.c;
-                    const int64_t rn = (r + 4 < r_end) ? r + 4 : r;
+                    const int rn = (r + 4 < r_end) ? r + 4 : r;
                     vm_request3nt(piece(rn, 0), piece(rn, 1), piece(rn, 2), nx);
-                    const int64_t g = r * 64 + lane;
+                    const int64_t g = (int64_t)r * 64 + lane;
                     uint32_t w[12];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
                     if (g < ng) {                                     // only the image's last round has lanes past the end; every round has
                         uint32_t pk[2] = {0u, 0u};                    // lane 0 inside, so the store below is one operation of the wave in
 #pragma unroll                                                        // every round -- the hand-counted vmcnt waits rely on that
-                        for (int k = 0; k < 16; ++k) { hadd(kb[k]); pk[k >> 3] |= (kb[k] >> 4) << (4 * (k & 7)); }
+                        for (int k = 0; k < 16; ++k) { hadd(kb[k]); pk[k >> 3] |= ((kb[k] >> 4) & 15u) << (4 * (k & 7)); }
                         if (kPlane) vm_store8(bins + g * 8, pk[0], pk[1]);
                     }
                     vm_wait48<kPlane ? 1 : 0>(nx);                    // the requested bytes are in; this round's store may still be on its way
@@ -838,6 +843,10 @@ static int blocks_per_image(const Job& j, int px_per_block) {
 
 hipError_t launch_threshold(const Job& j, hipStream_t s) {
     LFA_LAUNCH("k_init_info", k_init_info, dim3(j.H >= 4096 ? 8 : 2, j.n), dim3(256), 0, s, j);
+    if (j.wait_event) {                                   // lfa_chain_passes: the passes below start when the other handle's are done
+        const hipError_t e = hipStreamWaitEvent(s, j.wait_event, 0);
+        if (e != hipSuccess) return e;
+    }
     if (j.C == 3) {
         static const int mm_bpi = [] { const char* e = getenv("LFA_MM_BPI"); return e ? atoi(e) : 0; }();
         const dim3 grid(mm_bpi > 0 ? mm_bpi : blocks_per_image(j, 256 * 64), j.n);

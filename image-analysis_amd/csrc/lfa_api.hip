@@ -142,6 +142,7 @@ struct LfaContext {
     bool have_last = false;
     EventTimer* timer = nullptr;
     hipEvent_t passes_event = nullptr;     // see lfa_stream_wait_passes
+    LfaContext* after = nullptr;           // see lfa_chain_passes
     // Class plane on/off per call (colour images).  k_otsu_rgb counts the images that could use the plane; the two counters
     // are copied to pinned host memory behind the call's kernels and looked at -- without waiting -- when a later call is
     // set up: while fewer than half of the images could use it, the histogram pass does not write the plane at all
@@ -284,6 +285,7 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
     j.edges_i = (uint32_t*)w.edges_i.p;
     // class plane: colour images on the vector paths only (16-pixel groups in k_hist_rgb, 16-column groups in k_mask)
     j.passes_event = h->passes_event;
+    j.wait_event = h->after ? h->after->passes_event : nullptr;
     j.plane_stats = (uint32_t*)h->plane_stats.p;
     j.win_hint = (h->debug_flags & 32) ? 0 : h->win_hint;
     j.u16_lds_bins = (h->debug_flags & 16) ? lfa::kLdsBinsU16 : h->u16_max + 1;
@@ -733,6 +735,14 @@ int lfa_stream_wait_passes(LfaHandle producer, void* stream) {
     if (!producer) return fail(LFA_ERR_ARG, "null handle");
     LFA_ON_DEVICE(producer->device);
     LFA_HIP(hipStreamWaitEvent((hipStream_t)stream, producer->passes_event, 0));
+    return LFA_OK;
+}
+
+int lfa_chain_passes(LfaHandle consumer, LfaHandle producer) {
+    if (!consumer) return fail(LFA_ERR_ARG, "null handle");
+    if (producer == consumer) return fail(LFA_ERR_ARG, "a handle cannot follow itself (its calls are ordered already)");
+    if (producer && producer->device != consumer->device) return fail(LFA_ERR_ARG, "handles on devices %d and %d: chaining is per device", producer->device, consumer->device);
+    consumer->after = producer;
     return LFA_OK;
 }
 

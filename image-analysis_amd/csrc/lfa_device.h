@@ -110,18 +110,19 @@ __device__ inline double gray_u8(uint32_t p0, uint32_t p1, uint32_t p2) {
 }
 
 // ---- integer gray G = 2125*b0 + 7154*b1 + 721*b2 of pixel k (0..15) of a 48-byte group -----------------------------------
-// (k_threshold.hip explains why compares on G are exact).  The three bytes are brought to the low end of a dword
-// (shift / v_alignbyte) and multiplied with two v_dot4_u32_u8: weights split as hi*256 + lo, the fourth byte weighs 0.
+// (k_threshold.hip explains why compares on G are exact).  A pixel that straddles two dwords is brought together with
+// v_alignbyte; then two v_dot4_u32_u8: weights split as hi*256 + lo, placed where the pixel's bytes sit, the fourth byte weighs 0.
 __device__ inline uint32_t gray_G_from_dword(uint32_t px) {
     const uint32_t hi = __builtin_amdgcn_udot4(px, 0x00021B08u, 0u, false);       // 8, 27, 2
     return __builtin_amdgcn_udot4(px, 0x00D1F24Du, hi << 8, false);               // 77, 242, 209
 }
 __device__ inline uint32_t gray_G16(const uint32_t (&w)[12], int k) {             // k: compile-time constant after unrolling
     const int i = (3 * k) >> 2, s = (3 * k) & 3;
-    uint32_t px;
-    if (s == 0) px = w[i];
-    else if (s == 1) px = w[i] >> 8;
-    else px = __builtin_amdgcn_alignbyte(w[i + 1], w[i], s);
+    if (s == 1) {                                                                 // bytes 1-3 of the dword: the weights move instead
+        const uint32_t hi = __builtin_amdgcn_udot4(w[i], 0x021B0800u, 0u, false);
+        return __builtin_amdgcn_udot4(w[i], 0xD1F24D00u, hi << 8, false);
+    }
+    const uint32_t px = (s == 0) ? w[i] : __builtin_amdgcn_alignbyte(w[i + 1], w[i], s);
     return gray_G_from_dword(px);
 }
 

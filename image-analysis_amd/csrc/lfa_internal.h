@@ -47,6 +47,7 @@ struct Job {
     double* edges_g;         // [n][257]  gray-space bin edges (colour path)
     uint32_t* edges_i;       // [n][264]  the same as integer thresholds on G = 2125*b0 + 7154*b1 + 721*b2 (k_threshold.hip)
     hipEvent_t passes_event; // recorded on the launch stream right after the histogram pass (lfa_stream_wait_passes); may be null
+    hipEvent_t wait_event;   // the image passes of this call start after it (lfa_chain_passes); may be null
     uint32_t* plane_stats;   // [kStatsWords]  [4] longest analysis window of the call in rows (k_finalize); [0] colour images of this call whose mask could be decided from the class plane, [1] colour images
                              //      seen (k_otsu_rgb counts), [2] largest pixel value of the call's uint16 images, [3] uint16 images
                              //      seen (k_otsu_int); [5] sum, [8] number, [9] 65535 - smallest and [10] largest of the uint16 thresholds x_thr, [6] uint16 images whose

@@ -270,6 +270,15 @@ int lfa_timing_read(LfaHandle h, int max_entries, char* names, double* total_ms,
  * the memory bandwidth, and batch k's tail runs in their shadow. */
 int lfa_stream_wait_passes(LfaHandle producer, void* stream);
 
+/* The same ordering as a standing rule (no counterpart in the reference): from now on the whole-image passes of every
+ * detect/analyze call on `consumer` start when the passes (through the histogram) of `producer`'s most recent call are
+ * done -- the wait is enqueued inside the call, after its set-up kernels and right before its first image pass, so
+ * nothing but the passes themselves is held back.  With handles h0 .. h(k-1) taking consecutive batches in turn and
+ * h(i) chained after h(i-1) (h0 after h(k-1)), at most one batch is in its min/max or histogram pass at any time: those
+ * passes run at their stand-alone speed, one behind the other, and the tails of the batches before run beside them.
+ * producer NULL ends the rule.  Both handles must be on the same device; end the rule before destroying `producer`. */
+int lfa_chain_passes(LfaHandle consumer, LfaHandle producer);
+
 /* Block until everything enqueued on `stream` through this handle has finished. */
 int lfa_sync(LfaHandle h, void* stream);
 

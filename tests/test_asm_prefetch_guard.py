@@ -74,11 +74,20 @@ def _check(text):
                             # lane 0 of every round is inside the image (k_threshold.hip, comment at the plane store), and the
                             # hand-counted wait relies on exactly that -- the path is followed as if the store had been issued.
                             end = k                               # the skipped block ends at the label or at its jump to it
-                            while lines[end] != br.group(3) + ":" and lines[end] != "s_branch " + br.group(3):
+                            while end < len(lines) and lines[end] != br.group(3) + ":" and lines[end] != "s_branch " + br.group(3):
                                 end += 1
-                            skipped = sum(1 for x in lines[k:end] if x.startswith("global_store"))
+                            skipped = sum(1 for x in lines[k:end] if x.startswith("global_store")) if end < len(lines) else 0
                         todo.append((t, pending, younger + skipped))
-                        if not br.group(1):
+                        always = not br.group(1)
+                        if br.group(2) == "_execnz":
+                            # LLVM writes the uniform `break` of a loop as "s_cbranch_execnz <exit>" in a block of its own that
+                            # never changes exec; a running wave has a lane, so that branch is always taken (the loops that do
+                            # depend on exec clear lanes right before the branch)
+                            b0 = k - 2
+                            while b0 >= 0 and not lines[b0].endswith(":"):
+                                b0 -= 1
+                            always = not any(re.search(r"\bexec\b|^v_cmpx", x.split(",")[0]) for x in lines[b0 + 1:k - 1])
+                        if always:
                             break
     return requests
 

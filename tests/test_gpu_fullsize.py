@@ -99,9 +99,11 @@ def test_batch_properties_and_determinism():
     eng.close()
 
 
-def test_two_handles_chained_with_stream_wait_passes():
-    """Chunks alternating on two handles / streams, each chunk's passes chained to the previous chunk's histogram pass
-    (lfa_stream_wait_passes): same strips, profiles and peaks as one handle processing the chunks one after the other."""
+@pytest.mark.parametrize("rule,lanes", [("per call", 2), ("standing", 3)])
+def test_handles_chained_by_their_histogram_passes(rule, lanes):
+    """Chunks taking 2 / 3 handles + streams in turn, each chunk's passes chained to the previous chunk's histogram pass -- by a
+    wait enqueued before every call (lfa_stream_wait_passes) or as a standing rule between the handles (lfa_chain_passes, the
+    bench's schedule): same strips, profiles and peaks as one handle processing the chunks one after the other."""
     import ctypes as C
     import torch
     import image_analysis_amd._capi as capi
@@ -113,8 +115,12 @@ def test_two_handles_chained_with_stream_wait_passes():
     want, _ = ref_eng.analyze(imgs, mm_r, mm_c, max_strips=16)
     ref_eng.close()
     dev = torch.device("cuda", 0)
-    engs = [capi.Engine(device=0, max_h=H, max_w=W, max_batch=ch) for _ in range(2)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    engs = [capi.Engine(device=0, max_h=H, max_w=W, max_batch=ch) for _ in range(lanes)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+    if rule == "standing":
+        for i in range(lanes):
+            capi._check(capi.lib.lfa_chain_passes(engs[i]._h, engs[i - 1]._h))
+        assert capi.lib.lfa_chain_passes(engs[0]._h, engs[0]._h) == -1     # LFA_ERR_ARG: a handle cannot follow itself
     batch = capi.to_device(imgs, dev)
     ms, stride = 16, int(H * .6) + 1
     strips = capi.dev_bytes(n * ms * 24, dev); counts = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -122,11 +128,14 @@ def test_two_handles_chained_with_stream_wait_passes():
     prof = torch.zeros(n * ms * stride, dtype=torch.float64, device=dev); peaks = capi.dev_bytes(n * ms * 40, dev)
     torch.cuda.synchronize()
     ib = H * W * 3
+    turn = 0
     for rep in range(2):
-        for ci, b0 in enumerate(range(0, n, ch)):
-            st = C.c_void_p(streams[ci % 2].cuda_stream)
-            capi._check(capi.lib.lfa_stream_wait_passes(engs[(ci - 1) % 2]._h, st))
-            capi._check(capi.lib.lfa_analyze_batch(engs[ci % 2]._h, batch.data_ptr() + b0 * ib, capi.LFA_U8, ch, H, W, 3, mm_r, mm_c, 10,
+        for b0 in range(0, n, ch):
+            ci, turn = turn, turn + 1
+            st = C.c_void_p(streams[ci % lanes].cuda_stream)
+            if rule == "per call":
+                capi._check(capi.lib.lfa_stream_wait_passes(engs[(ci - 1) % lanes]._h, st))
+            capi._check(capi.lib.lfa_analyze_batch(engs[ci % lanes]._h, batch.data_ptr() + b0 * ib, capi.LFA_U8, ch, H, W, 3, mm_r, mm_c, 10,
                         strips.data_ptr() + b0 * ms * 24, ms, counts.data_ptr() + b0 * 4, info.data_ptr() + b0 * 104,
                         rois.data_ptr() + b0 * ms * 20, prof.data_ptr() + b0 * ms * stride * 8, stride,
                         peaks.data_ptr() + b0 * ms * 40, st))
@@ -141,6 +150,8 @@ def test_two_handles_chained_with_stream_wait_passes():
         for k in range(cn[i]):
             assert np.array_equal(pr_np[i, k, :pk_np[i, k]["length"]], w_profiles[k])
             assert pk_np[i, k] == w_peaks[k]
+    for e in engs:
+        capi._check(capi.lib.lfa_chain_passes(e._h, None))       # the rule ends before a producer goes away
     for e in engs:
         e.close()
 
