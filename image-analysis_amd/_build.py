@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "obj")
 LIB = os.path.join(HERE, "liblfa_hip.so")
-SOURCES = ["lfa_api.hip", "k_threshold.hip", "k_mask.hip", "k_label.hip", "k_regions.hip", "k_profile.hip", "k_gaussian.hip"]
+SOURCES = ["lfa_api.hip", "k_threshold.hip", "k_mask.hip", "k_label.hip", "k_regions.hip", "k_profile.hip", "k_gaussian.hip", "k_lines.hip"]
 # -ffp-contract=off: the kernels reproduce numpy's float64 results bit for bit; fused multiply-adds appear only where
 # the reference's BLAS uses them and are then written as fma() explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall"] + os.environ.get("LFA_EXTRA_FLAGS", "").split() + [

@@ -29,7 +29,12 @@ INFO_DT = np.dtype([("xmin", "<i4"), ("xmax", "<i4"), ("v_thr", "<i4"), ("x_thr"
                     ("g_thr", "<f8"), ("otsu_bin", "<i4"), ("all_equal", "<i4"), ("ambiguous", "<u4"),
                     ("n_runs", "<i4"), ("n_labels", "<i4"), ("label00", "<i4"), ("n_candidates", "<i4"),
                     ("n_accepted", "<i4"), ("n_strips", "<i4"), ("status", "<i4")], align=True)
+LINEBOX_DT = np.dtype([("minr", "<i4"), ("maxr", "<i4"), ("minc", "<i4"), ("maxc", "<i4")], align=True)
+LINESINFO_DT = np.dtype([("umin", "<i4"), ("umax", "<i4"), ("cmin", "<i4"), ("cmax", "<i4"), ("p80", "<f8"), ("p99", "<f8"),
+                         ("n_labels", "<i4"), ("n_boxes", "<i4"), ("status", "<i4"), ("pad", "<i4")], align=True)
+LDBG_GAUSS, LDBG_U16, LDBG_LEVELS, LDBG_ROOTS, LDBG_LVAL = 0, 1, 2, 3, 4
 assert STRIP_DT.itemsize == 24 and ROI_DT.itemsize == 20 and PEAKS_DT.itemsize == 40 and INFO_DT.itemsize == 104
+assert LINEBOX_DT.itemsize == 16 and LINESINFO_DT.itemsize == 48
 
 
 class LfaError(RuntimeError):
@@ -68,6 +73,8 @@ def _load():
     lib.lfa_static_workspace_bytes.restype = i64
     lib.lfa_gaussian_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, dbl, vp, i32, vp, i32, vp]
     lib.lfa_debug_fetch.argtypes = [vp, i32, i32, vp, i64, vp]
+    lib.lfa_detect_lines_batch.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp]
+    lib.lfa_lines_debug_fetch.argtypes = [vp, i32, i32, vp, i64, vp]
     lib.lfa_sync.argtypes = [vp, vp]
     lib.lfa_stream_wait_passes.argtypes = [vp, vp]
     lib.lfa_chain_passes.argtypes = [vp, vp]
@@ -75,7 +82,8 @@ def _load():
     lib.lfa_timing_read.argtypes = [vp, i32, vp, vp, vp, vp]
     for name in ("lfa_timing_enable", "lfa_timing_read","lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant", "lfa_detect_batch",
                  "lfa_profile_batch", "lfa_profile_lut_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch",
-                 "lfa_debug_fetch", "lfa_sync", "lfa_stream_wait_passes", "lfa_chain_passes", "lfa_analyze_batch_static", "lfa_reserve"):
+                 "lfa_debug_fetch", "lfa_sync", "lfa_stream_wait_passes", "lfa_chain_passes", "lfa_analyze_batch_static", "lfa_reserve",
+                 "lfa_detect_lines_batch", "lfa_lines_debug_fetch"):
         getattr(lib, name).restype = i32
     return lib
 
@@ -87,7 +95,7 @@ EXPORTED = ("lfa_version", "lfa_last_error", "lfa_create", "lfa_destroy", "lfa_s
             "lfa_detect_batch", "lfa_profile_batch", "lfa_profile_lut_batch", "lfa_peaks_batch", "lfa_analyze_batch",
             "lfa_gaussian_batch", "lfa_debug_fetch", "lfa_sync", "lfa_timing_enable", "lfa_timing_read",
             "lfa_stream_wait_passes", "lfa_chain_passes", "lfa_analyze_batch_static", "lfa_static_workspace_bytes", "lfa_reserve",
-            "lfa_workspace_bytes")
+            "lfa_workspace_bytes", "lfa_detect_lines_batch", "lfa_lines_debug_fetch")
 
 
 def _check(rc):
@@ -472,6 +480,62 @@ class Engine:
                                       int(bool(out_f32)), current_stream_ptr(self.device)))
         shape = (n, H, W) if Cc == 1 else (n, H, W, Cc)
         return out.cpu().numpy().reshape(shape)
+
+    @staticmethod
+    def scipy_gaussian_taps(sigma, radius):
+        """scipy.ndimage._filters._gaussian_kernel1d (order 0) with this host's numpy exp()"""
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+        return np.ascontiguousarray(phi / phi.sum(), dtype=np.float64)
+
+    def detect_lines(self, images: np.ndarray, max_boxes=256, host_weights=True):
+        """detect_lines (detection.py:156-201) of every image of a (n,H,W) uint8 / uint16 batch.
+        Returns (list of LINEBOX_DT arrays in the reference's order, LINESINFO_DT array)."""
+        torch = _torch()
+        images = np.asarray(images)
+        if images.ndim != 3:
+            raise ValueError("expected a batch (n,H,W) of 2-D images")
+        n, H, W = images.shape
+        code = np_dtype_code(images.dtype)
+        w9 = self.scipy_gaussian_taps(1.0, 4) if host_weights else None
+        w3 = self.scipy_gaussian_taps((3 - 1) / 6.0, 1) if host_weights else None
+        out_b, out_i = [], []
+        for b0 in range(0, n, self.max_batch):
+            m = min(n, b0 + self.max_batch) - b0
+            t = to_device(images[b0:b0 + m], self.device)
+            cap = int(max_boxes)
+            while True:
+                boxes = dev_bytes(m * cap * LINEBOX_DT.itemsize, self.device)
+                counts = torch.zeros(m, dtype=torch.int32, device=self.device)
+                info = dev_bytes(m * LINESINFO_DT.itemsize, self.device)
+                _check(lib.lfa_detect_lines_batch(self._h, t.data_ptr(), code, m, H, W, w9.ctypes.data if host_weights else None,
+                                                  w3.ctypes.data if host_weights else None, boxes.data_ptr(), cap,
+                                                  counts.data_ptr(), info.data_ptr(), current_stream_ptr(self.device)))
+                inf = from_device(info, LINESINFO_DT, m)
+                if (inf["status"] & 1).any() and cap < 65536:
+                    cap = min(65536, cap * 8)
+                    continue
+                break
+            if (inf["status"] & 1).any():
+                raise LfaError(-3, "detect_lines: more than 65536 boxes per image")
+            cn = from_device(counts, np.int32, m)
+            bx = from_device(boxes, LINEBOX_DT, m * cap).reshape(m, cap)
+            out_b += [bx[i, :cn[i]].copy() for i in range(m)]
+            out_i.append(inf.copy())
+        return out_b, np.concatenate(out_i)
+
+    def lines_debug(self, image_index, what, H, W):
+        """Intermediate `what` (LDBG_*) of image `image_index` of the last detect_lines call."""
+        torch = _torch()
+        dt, count = {LDBG_GAUSS: (torch.float64, H * W), LDBG_U16: (torch.int16, H * W), LDBG_LEVELS: (torch.int16, H * W),
+                     LDBG_ROOTS: (torch.int32, H * W), LDBG_LVAL: (torch.float64, 16384)}[what]
+        out = torch.empty(count, dtype=dt, device=self.device)
+        _check(lib.lfa_lines_debug_fetch(self._h, image_index, what, out.data_ptr(), out.numel() * out.element_size(),
+                                         current_stream_ptr(self.device)))
+        a = out.cpu().numpy()
+        if dt == torch.int16:
+            a = a.view(np.uint16)
+        return a.reshape(H, W) if count == H * W else a
 
     def debug(self, image_index, what, H, W):
         torch = _torch()

@@ -1,0 +1,419 @@
+// k_lines.hip -- detect_lines (LFA-Image_Analysis/detection.py:156-201), SURVEY.md section 8f.3  (gfx950)
+//
+// The reference defines this function and never calls it.  Its stages after the first Gaussian (detection.py:166, done by
+// k_gaussian) are restated here one kernel per dependency -- every stage needs a whole-image scalar of the one before
+// (extremes, tile histograms, percentiles), so nothing fuses across them.  Reference arithmetic (SP = /root/reference/
+// image-analysis/lib/python3.10/site-packages):
+//   threshold_local(gaussian, block 3, 'reflect')   SP/skimage/filters/thresholding.py:236-243 -> scipy correlate1d, 3 taps
+//   adjust_gamma(float image, 0.5)                  SP/skimage/exposure/exposure.py:679   (x / 1.0) ** 0.5 * 1.0 * 1
+//   equalize_adapthist(clip_limit 0.05)             SP/skimage/exposure/_adapthist.py:72-89, _clahe :117-226, clip_histogram
+//                                                   :248-280, map_histogram :305-310 ; img_as_uint SP/skimage/util/dtype.py
+//   np.percentile (80, 99), method 'linear'         numpy lib/_function_base_impl.py _quantile / _lerp
+//   rescale_intensity(in_range=(p80, p99), (0, 1))  SP/skimage/exposure/exposure.py:577-589
+//   label of a non-boolean image                    SP/skimage/measure/_label.py:30-120 (equal values, 8-connected, 0 = background,
+//                                                   numbered in raster order of the first pixel)
+//   regionprops .bbox + the area / shape filter     detection.py:187-200
+// After CLAHE the image holds at most 16384 distinct values (the uint16 `levels`), and everything downstream is a
+// monotone function of the level: percentiles come from the level histogram, the float the reference would hold for a
+// level is computed once per level (`lval`), and "equal float values" becomes "equal class" with one class per distinct
+// value of lval (class 0 = value 0 = background).  Components are labelled on the class image with a pixel union-find
+// whose roots are the smallest pixel index, i.e. the raster-first pixel the reference numbers its labels by.
+// -ffp-contract=off (the build's flag): every float operation below is the single IEEE operation numpy performs.
+#include "lfa_internal.h"
+#include "lfa_device.h"
+
+namespace lfa {
+
+// ---- stage 2: local threshold, gamma 0.5, img_as_uint ---------------------------------------------------------------------
+__device__ __forceinline__ int reflect_half(int i, int n) {         // scipy 'reflect' (d c b a | a b c d | d c b a), |overshoot| <= 1
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
+__global__ __launch_bounds__(256) void k_lines_local(LinesJob j) {
+    const int img = blockIdx.y;
+    const int64_t npix = (int64_t)j.H * j.W;
+    const double* g = j.g + (int64_t)img * npix;
+    uint16_t* u = j.u + (int64_t)img * npix;
+    int lo = 65535, hi = 0;
+    int over = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(p / j.W), x = (int)(p - (int64_t)y * j.W);
+        const int ym = reflect_half(y - 1, j.H), yp = reflect_half(y + 1, j.H);
+        const int xm = reflect_half(x - 1, j.W), xp = reflect_half(x + 1, j.W);
+        auto col = [&](int xx) -> double {                            // axis 0 first (scipy.ndimage.gaussian_filter)
+            double t = g[(int64_t)y * j.W + xx] * j.w0;
+            t += (g[(int64_t)ym * j.W + xx] + g[(int64_t)yp * j.W + xx]) * j.w1;
+            return t;
+        };
+        double t = col(x) * j.w0;
+        t += (col(xm) + col(xp)) * j.w1;
+        const double gv = g[p];
+        const double xg = (t - 0.0 > 0.0) ? gv * 1.0 : gv * 0.0;      // image_copy * (thresholded_image > 0), detection.py:170
+        const double s = sqrt(xg / 1.0) * 1.0 * 1.0;                  // ((image / scale) ** gamma) * scale * gain
+        if (s > 1.0 || s < -1.0) over = 1;                            // img_as_uint refuses such an image
+        double v = rint(s * 65535.0);
+        v = v < 0.0 ? 0.0 : (v > 65535.0 ? 65535.0 : v);
+        const int q = (int)v;
+        u[p] = (uint16_t)q;
+        lo = min(lo, q); hi = max(hi, q);
+    }
+    lo = wave_min_i32(lo); hi = wave_max_i32(hi);
+    if ((threadIdx.x & 63) == 0) { atomicMin(&j.info[img].umin, lo); atomicMax(&j.info[img].umax, hi); }
+    if (over) atomicOr(&j.info[img].status, 2);
+}
+
+__global__ void k_lines_init(LinesJob j) {
+    const int img = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        LfaLinesInfo z;
+        z.umin = 65535; z.umax = 0; z.cmin = 65535; z.cmax = 0; z.p80 = 0.0; z.p99 = 0.0; z.n_labels = 0; z.n_boxes = 0; z.status = 0; z.pad = 0;
+        j.info[img] = z;
+    }
+    for (int k = t; k < 16384; k += gridDim.x * blockDim.x) j.lhist[(int64_t)img * 16384 + k] = 0u;
+}
+
+// ---- stage 3: value -> CLAHE bin table --------------------------------------------------------------------------------------
+// rescale_intensity(image, out_range=(0, 16383)), np.round, cast (_adapthist.py:74-76), then lut //= 65 (:133-135)
+__global__ void k_lines_binlut(LinesJob j) {
+    const int img = blockIdx.y;
+    const double imin = (double)j.info[img].umin, imax = (double)j.info[img].umax;
+    uint8_t* lut = j.binlut + (int64_t)img * 65536;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < 65536; v += gridDim.x * blockDim.x) {
+        double c = (double)v;
+        c = c < imin ? imin : (c > imax ? imax : c);
+        double r;
+        if (imin != imax) { r = (c - imin) / (imax - imin); r = r * (16383.0 - 0.0) + 0.0; }
+        else r = c < 0.0 ? 0.0 : (c > 16383.0 ? 16383.0 : c);
+        const int v14 = (int)rint(r);
+        lut[v] = (uint8_t)(v14 / 65);
+    }
+}
+
+// np.pad(mode='reflect') of an axis of n samples: index i of the unpadded axis, any overshoot (period 2 (n - 1))
+__device__ __forceinline__ int reflect_pad(int i, int n) {
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - i;
+}
+
+// ---- stage 4: one block per CLAHE tile: histogram, clip_histogram, map_histogram --------------------------------------------
+__global__ __launch_bounds__(256) void k_clahe_tiles(LinesJob j) {
+    __shared__ int h[256];
+    __shared__ int s_sum[4];
+    const int img = blockIdx.y, tile = blockIdx.x, ty = tile / j.ntx, tx = tile % j.ntx;
+    const int b = threadIdx.x;
+    const int64_t npix = (int64_t)j.H * j.W;
+    const uint16_t* u = j.u + (int64_t)img * npix;
+    const uint8_t* lut = j.binlut + (int64_t)img * 65536;
+    h[b] = 0;
+    __syncthreads();
+    const int y0 = j.kh / 2 + ty * j.kh, x0 = j.kw / 2 + tx * j.kw;       // padded coordinates of the tile (:145-146)
+    const int n_el = j.kh * j.kw;
+    for (int e = b; e < n_el; e += 256) {
+        const int yy = reflect_pad(y0 + e / j.kw - j.sy, j.H), xx = reflect_pad(x0 + e % j.kw - j.sx, j.W);
+        atomicAdd(&h[lut[u[(int64_t)yy * j.W + xx]]], 1);
+    }
+    __syncthreads();
+    auto block_sum = [&](int v) -> int {                                  // every thread gets the sum
+        v = (int)wave_sum_u32((uint32_t)v);
+        __syncthreads();
+        if ((b & 63) == 0) s_sum[b >> 6] = v;
+        __syncthreads();
+        return s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    };
+    // clip_histogram (_adapthist.py:248-280); thread b owns bin b
+    const int clim = j.clim;
+    int hv = h[b];
+    int n_excess = block_sum(hv > clim ? hv - clim : 0);
+    if (hv > clim) hv = clim;
+    const int bin_incr = n_excess / 256;
+    const int upper = clim - bin_incr;
+    const bool low = hv < upper;
+    n_excess -= block_sum(low ? 1 : 0) * bin_incr;
+    if (low) hv += bin_incr;
+    const bool mid = hv >= upper && hv < clim;
+    n_excess += block_sum(mid ? hv - clim : 0);
+    if (mid) hv = clim;
+    while (n_excess > 0) {
+        const int before = n_excess;
+        for (int index = 0; index < 256; ++index) {
+            const bool under = hv < clim;
+            const int cnt = block_sum(under ? 1 : 0);
+            int step = cnt / n_excess;
+            if (step < 1) step = 1;
+            const bool sel = under && b >= index && ((b - index) % step) == 0;
+            if (sel) hv += 1;
+            n_excess -= block_sum(sel ? 1 : 0);
+            if (n_excess <= 0) break;
+        }
+        if (before == n_excess) break;
+    }
+    __syncthreads();
+    h[b] = hv;
+    __syncthreads();
+    // map_histogram (:305-310): cumulative sum, scale, clip, truncate
+    if (b == 0) { int a = 0; for (int k = 0; k < 256; ++k) { a += h[k]; h[k] = a; } }
+    __syncthreads();
+    double m = (double)h[b];
+    m *= (double)(16383 - 0) / (double)n_el;
+    m += 0.0;
+    if (m > 16383.0) m = 16383.0;
+    j.maps[((int64_t)img * j.nty * j.ntx + tile) * 256 + b] = (int32_t)m;
+}
+
+// ---- stage 5: bilinear blend of the four neighbouring tile maps (_adapthist.py:176-210) ------------------------------------
+__global__ __launch_bounds__(256) void k_clahe_blend(LinesJob j) {
+    __shared__ uint32_t sh[16384];                                       // level histogram of this block's pixels
+    for (int k = threadIdx.x; k < 16384; k += 256) sh[k] = 0u;
+    __syncthreads();
+    const int img = blockIdx.y;
+    const int64_t npix = (int64_t)j.H * j.W;
+    const uint16_t* u = j.u + (int64_t)img * npix;
+    const uint8_t* lut = j.binlut + (int64_t)img * 65536;
+    const int32_t* maps = j.maps + (int64_t)img * j.nty * j.ntx * 256;
+    uint16_t* lv = j.levels + (int64_t)img * npix;
+    int lo = 65535, hi = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(p / j.W), x = (int)(p - (int64_t)y * j.W);
+        const int py = y + j.sy, px = x + j.sx;
+        const int by = py / j.kh, bx = px / j.kw;
+        const double cy = (double)(py % j.kh) / (double)j.kh, cx = (double)(px % j.kw) / (double)j.kw;
+        const int bin = lut[u[p]];
+        float res = 0.0f;
+#pragma unroll
+        for (int e0 = 0; e0 < 2; ++e0) {
+#pragma unroll
+            for (int e1 = 0; e1 < 2; ++e1) {
+                const int ty = min(max(by + e0 - 1, 0), j.nty - 1), tx = min(max(bx + e1 - 1, 0), j.ntx - 1);
+                const double coeff = (e1 ? cx : 1.0 - cx) * (e0 ? cy : 1.0 - cy);
+                const double m = (double)maps[((int64_t)ty * j.ntx + tx) * 256 + bin];
+                res = res + (float)(m * coeff);
+            }
+        }
+        const int q = (int)res;                                          // result.astype(uint16): truncation
+        lv[p] = (uint16_t)q;
+        atomicAdd(&sh[q & 16383], 1u);
+        lo = min(lo, q); hi = max(hi, q);
+    }
+    lo = wave_min_i32(lo); hi = wave_max_i32(hi);
+    if ((threadIdx.x & 63) == 0 && hi >= lo) { atomicMin(&j.info[img].cmin, lo); atomicMax(&j.info[img].cmax, hi); }
+    __syncthreads();
+    uint32_t* gh = j.lhist + (int64_t)img * 16384;
+    for (int k = threadIdx.x; k < 16384; k += 256) if (sh[k]) atomicAdd(&gh[k], sh[k]);
+}
+
+// ---- stage 6: percentiles, the float value of every level, classes of equal value -----------------------------------------
+// rescale_intensity of a float64 image with in_range (lo, hi) and out_range (0, 1)  (exposure.py:577-589)
+__device__ __forceinline__ double rescale_unit(double x, double lo, double hi) {
+    const double c = x < lo ? lo : (x > hi ? hi : x);
+    if (lo != hi) return (c - lo) / (hi - lo) * (1.0 - 0.0) + 0.0;
+    return c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+}
+
+__global__ __launch_bounds__(1024) void k_lines_levels(LinesJob j) {
+    __shared__ uint32_t part[1024];
+    __shared__ int s_level[4];
+    __shared__ double s_p[2];
+    const int img = blockIdx.x, t = threadIdx.x;
+    uint32_t* gh = j.lhist + (int64_t)img * 16384;                       // becomes its own inclusive prefix
+    uint32_t* cum = gh;
+    LfaLinesInfo* inf = &j.info[img];
+    uint32_t loc[16], a = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { a += gh[t * 16 + k]; loc[k] = a; }
+    part[t] = a;
+    __syncthreads();
+    if (t == 0) { uint32_t s = 0; for (int k = 0; k < 1024; ++k) { const uint32_t v = part[k]; part[k] = s; s += v; } }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cum[t * 16 + k] = part[t] + loc[k];
+    __syncthreads();
+    const double cmin = (double)inf->cmin, cmax = (double)inf->cmax;
+    const int64_t n = (int64_t)j.H * j.W;
+    // np.percentile(e, (80, 99)): virtual index (n - 1) * q, floor / +1 neighbours, _lerp
+    int64_t want[4];
+    double gam[2];
+    for (int k = 0; k < 2; ++k) {
+        const double quant = (k == 0 ? 80.0 : 99.0) / 100.0;
+        const double vi = (double)(n - 1) * quant;
+        int64_t prev = (int64_t)floor(vi), next = prev + 1;
+        if (vi >= (double)(n - 1)) { prev = n - 1; next = n - 1; }       // (index -1 of the sorted array)
+        gam[k] = vi - floor(vi);
+        want[2 * k] = prev; want[2 * k + 1] = next;
+    }
+    if (t < 4) {                                                         // smallest level L with cum[L] > rank
+        int lo = 0, hi = 16383;
+        const uint32_t rank = (uint32_t)want[t];
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cum[mid] > rank) hi = mid; else lo = mid + 1; }
+        s_level[t] = lo;
+    }
+    __syncthreads();
+    if (t < 2) {
+        const double va = rescale_unit((double)s_level[2 * t], cmin, cmax), vb = rescale_unit((double)s_level[2 * t + 1], cmin, cmax);
+        const double g = gam[t], diff = vb - va;
+        double r = va + diff * g;
+        if (g >= 0.5) r = vb - diff * (1.0 - g);
+        s_p[t] = r;
+    }
+    __syncthreads();
+    const double p80 = s_p[0], p99 = s_p[1];
+    if (t == 0) { inf->p80 = p80; inf->p99 = p99; }
+    // value the reference holds for each level after both rescales; a new class wherever it differs from the level below
+    double* lval = j.lval + (int64_t)img * 16384;
+    uint16_t* cls = j.cls + (int64_t)img * 16384;
+    uint32_t f = 0;
+    double v[16];
+    double below = (t == 0) ? 0.0 : rescale_unit(rescale_unit((double)(t * 16 - 1), cmin, cmax), p80, p99);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        v[k] = rescale_unit(rescale_unit((double)(t * 16 + k), cmin, cmax), p80, p99);
+        lval[t * 16 + k] = v[k];
+        if (v[k] != below) ++f;                                          // (level 0 against 0.0: background stays class 0)
+        loc[k] = f;
+        below = v[k];
+    }
+    __syncthreads();
+    part[t] = f;
+    __syncthreads();
+    if (t == 0) { uint32_t s = 0; for (int k = 0; k < 1024; ++k) { const uint32_t x = part[k]; part[k] = s; s += x; } }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cls[t * 16 + k] = (v[k] == 0.0) ? (uint16_t)0 : (uint16_t)(part[t] + loc[k]);
+}
+
+// ---- stage 7: components of equal class, 8-connected ------------------------------------------------------------------------
+__device__ __forceinline__ int ccl_find(const int32_t* parent, int x) {
+    int p = parent[x];
+    while (p != x) { x = p; p = parent[x]; }
+    return x;
+}
+
+__device__ __forceinline__ void ccl_union(int32_t* parent, int a, int b) {
+    for (;;) {
+        a = ccl_find(parent, a); b = ccl_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int s = a; a = b; b = s; }                    // the larger root hangs under the smaller one
+        const int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_init(LinesJob j) {
+    const int img = blockIdx.y;
+    const int64_t npix = (int64_t)j.H * j.W;
+    int32_t* parent = j.parent + (int64_t)img * npix;
+    int4* bbox = (int4*)(j.bbox + (int64_t)img * npix * 4);
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        parent[p] = (int)p;
+        bbox[p] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_merge(LinesJob j) {
+    const int img = blockIdx.y;
+    const int64_t npix = (int64_t)j.H * j.W;
+    const uint16_t* lv = j.levels + (int64_t)img * npix;
+    const uint16_t* cls = j.cls + (int64_t)img * 16384;
+    int32_t* parent = j.parent + (int64_t)img * npix;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(p / j.W), x = (int)(p - (int64_t)y * j.W);
+        const uint16_t c = cls[lv[p] & 16383];
+        if (!c) continue;
+        if (x > 0 && cls[lv[p - 1] & 16383] == c) ccl_union(parent, (int)p, (int)p - 1);
+        if (y > 0) {
+            const int64_t q = p - j.W;
+            if (cls[lv[q] & 16383] == c) ccl_union(parent, (int)p, (int)q);
+            if (x > 0 && cls[lv[q - 1] & 16383] == c) ccl_union(parent, (int)p, (int)q - 1);
+            if (x + 1 < j.W && cls[lv[q + 1] & 16383] == c) ccl_union(parent, (int)p, (int)q + 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
+    const int img = blockIdx.y;
+    const int64_t npix = (int64_t)j.H * j.W;
+    const uint16_t* lv = j.levels + (int64_t)img * npix;
+    const uint16_t* cls = j.cls + (int64_t)img * 16384;
+    int32_t* parent = j.parent + (int64_t)img * npix;
+    int32_t* bbox = j.bbox + (int64_t)img * npix * 4;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        if (!cls[lv[p] & 16383]) { parent[p] = -1; continue; }           // background
+        const int r = ccl_find(parent, (int)p);
+        parent[p] = r;                                                   // (a root keeps itself; others only ever point to smaller indices)
+        const int y = (int)(p / j.W), x = (int)(p - (int64_t)y * j.W);
+        atomicMin(&bbox[4 * (int64_t)r + 0], y); atomicMin(&bbox[4 * (int64_t)r + 1], x);
+        atomicMax(&bbox[4 * (int64_t)r + 2], y + 1); atomicMax(&bbox[4 * (int64_t)r + 3], x + 1);
+    }
+}
+
+// one candidate record per component that passes detection.py:191-199: root pixel, minr, maxr
+__global__ __launch_bounds__(256) void k_ccl_collect(LinesJob j) {
+    const int img = blockIdx.y;
+    const int64_t npix = (int64_t)j.H * j.W;
+    const int32_t* parent = j.parent + (int64_t)img * npix;
+    const int32_t* bbox = j.bbox + (int64_t)img * npix * 4;
+    const double min_area = (double)j.W * ((double)j.H * 0.0065), max_area = (double)j.W * ((double)j.H * 0.04);   // :159-160
+    int32_t* cand = j.cand + (int64_t)img * j.cap * 3;
+    uint32_t roots = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        if (parent[p] != (int)p) continue;
+        ++roots;
+        const int minr = bbox[4 * p], minc = bbox[4 * p + 1], maxr = bbox[4 * p + 2], maxc = bbox[4 * p + 3];
+        const int64_t area = (int64_t)(maxc - minc) * (maxr - minr);
+        // wider than tall and min_area < area < max_area: the box is widened to the whole image width and kept (:193-200)
+        if ((maxc - minc) > (maxr - minr) && (double)area > min_area && (double)area < max_area) {
+            const int k = atomicAdd(&j.info[img].n_boxes, 1);
+            if (k < j.cap) { cand[3 * k] = (int)p; cand[3 * k + 1] = minr; cand[3 * k + 2] = maxr; }
+        }
+    }
+    roots = wave_sum_u32(roots);
+    if ((threadIdx.x & 63) == 0 && roots) atomicAdd(&j.info[img].n_labels, (int)roots);
+}
+
+// regionprops order = label order = raster order of the first pixel = ascending root index
+__global__ __launch_bounds__(256) void k_lines_emit(LinesJob j, LfaLineBox* out, int32_t* counts, int max_boxes) {
+    const int img = blockIdx.x;
+    LfaLinesInfo* inf = &j.info[img];
+    const int total = inf->n_boxes, m = min(total, j.cap);
+    const int32_t* cand = j.cand + (int64_t)img * j.cap * 3;
+    for (int k = threadIdx.x; k < m; k += blockDim.x) {
+        const int root = cand[3 * k];
+        int rank = 0;
+        for (int q = 0; q < m; ++q) rank += cand[3 * q] < root;
+        if (rank < max_boxes) {
+            LfaLineBox b; b.minr = cand[3 * k + 1]; b.maxr = cand[3 * k + 2]; b.minc = 0; b.maxc = j.W;
+            out[(int64_t)img * max_boxes + rank] = b;
+        }
+    }
+    if (threadIdx.x == 0) {
+        counts[img] = min(total, max_boxes);
+        if (total > max_boxes || total > j.cap) atomicOr(&inf->status, 1);
+    }
+}
+
+hipError_t launch_lines(const LinesJob& j, LfaLineBox* out, int32_t* counts, int max_boxes, hipStream_t s) {
+    const int64_t npix = (int64_t)j.H * j.W;
+    int bpi = (int)((npix + 256 * 16 - 1) / (256 * 16));
+    const int want = (4096 + j.n - 1) / j.n;
+    if (bpi > want) bpi = want;
+    if (bpi < 1) bpi = 1;
+    const dim3 grid(bpi, j.n), blk(256);
+    LFA_LAUNCH("k_lines_init", k_lines_init, dim3(4, j.n), blk, 0, s, j);
+    LFA_LAUNCH("k_lines_local", k_lines_local, grid, blk, 0, s, j);
+    LFA_LAUNCH("k_lines_binlut", k_lines_binlut, dim3(16, j.n), blk, 0, s, j);
+    LFA_LAUNCH("k_clahe_tiles", k_clahe_tiles, dim3(j.nty * j.ntx, j.n), blk, 0, s, j);
+    LFA_LAUNCH("k_clahe_blend", k_clahe_blend, grid, blk, 0, s, j);
+    LFA_LAUNCH("k_lines_levels", k_lines_levels, dim3(j.n), dim3(1024), 0, s, j);
+    LFA_LAUNCH("k_ccl_init", k_ccl_init, grid, blk, 0, s, j);
+    LFA_LAUNCH("k_ccl_merge", k_ccl_merge, grid, blk, 0, s, j);
+    LFA_LAUNCH("k_ccl_boxes", k_ccl_boxes, grid, blk, 0, s, j);
+    LFA_LAUNCH("k_ccl_collect", k_ccl_collect, grid, blk, 0, s, j);
+    LFA_LAUNCH("k_lines_emit", k_lines_emit, dim3(j.n), blk, 0, s, j, out, counts, max_boxes);
+    return hipGetLastError();
+}
+
+}  // namespace lfa

@@ -161,9 +161,15 @@ struct LfaContext {
     bool u16_have_pred = false, u16_plane_on = true, pending_had_pred = false;
     int u16_thr_mean = 0, u16_thr_spread = 0;   // mean and (largest - smallest) threshold of that call
     int win_hint = 0;                      // longest analysis window of the last completed call (rows), 0 = unknown
+    // detect_lines workspace (lfa_detect_lines_batch), allocated by the first call that needs it
+    Buf ln_g, ln_u, ln_binlut, ln_maps, ln_levels, ln_lhist, ln_lval, ln_cls, ln_parent, ln_bbox, ln_cand, ln_info;
+    lfa::LinesJob lines_last{};
+    bool have_lines = false;
     std::vector<Buf*> all() {
         std::vector<Buf*> v = ws.all();
         v.push_back(&lut8); v.push_back(&lut16); v.push_back(&plane_stats); v.push_back(&roi_idx);
+        for (Buf* b : {&ln_g, &ln_u, &ln_binlut, &ln_maps, &ln_levels, &ln_lhist, &ln_lval, &ln_cls, &ln_parent, &ln_bbox, &ln_cand, &ln_info})
+            v.push_back(b);
         return v;
     }
 };
@@ -678,6 +684,90 @@ int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H,
     j.aligned16 = (((uintptr_t)images & 15) == 0 && (j.img_bytes & 15) == 0) ? 1 : 0;
     TimerScope ts(h);
     LFA_HIP(lfa::launch_gaussian_w(j, w, radius, out, out_f32, (hipStream_t)stream));
+    return LFA_OK;
+}
+
+int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W,
+                           const double* w_sigma1, const double* w_local,
+                           LfaLineBox* out_boxes, int max_boxes, int32_t* out_counts, LfaLinesInfo* out_info, void* stream) {
+    int rc = check_images(h, images, dtype, n, H, W, 1);
+    if (rc) return rc;
+    if (!out_boxes || !out_counts) return fail(LFA_ERR_ARG, "null output pointer");
+    if (max_boxes < 1 || max_boxes > 65536) return fail(LFA_ERR_ARG, "max_boxes must be in [1,65536]");
+    if ((long long)H * W > (1ll << 30)) return fail(LFA_ERR_UNSUPPORTED, "images above 2^30 pixels are not supported");
+    // scipy.ndimage._filters._gaussian_kernel1d: exp(-0.5 / sigma^2 * x^2), normalised by the plain sum
+    auto taps = [](double sigma, int radius, double* w) {
+        const double sigma2 = sigma * sigma;
+        double sum = 0.0;
+        for (int k = -radius; k <= radius; ++k) w[k + radius] = std::exp(-0.5 / sigma2 * (double)(k * k));
+        for (int k = 0; k < 2 * radius + 1; ++k) sum += w[k];
+        for (int k = 0; k < 2 * radius + 1; ++k) w[k] /= sum;
+    };
+    double w9[9], w3[3];
+    if (w_sigma1) { for (int k = 0; k < 9; ++k) w9[k] = w_sigma1[k]; } else taps(1.0, 4, w9);
+    if (w_local) { for (int k = 0; k < 3; ++k) w3[k] = w_local[k]; } else taps((3 - 1) / 6.0, 1, w3);
+    for (int k = 0; k < 4; ++k) if (w9[k] != w9[8 - k]) return fail(LFA_ERR_UNSUPPORTED, "kernel taps must be symmetric (scipy's correlate1d symmetric path)");
+    if (w3[0] != w3[2]) return fail(LFA_ERR_UNSUPPORTED, "kernel taps must be symmetric (scipy's correlate1d symmetric path)");
+    LFA_ON_DEVICE(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    lfa::LinesJob j{};
+    j.n = n; j.H = H; j.W = W;
+    j.kh = H / 8 > 1 ? H / 8 : 1; j.kw = W / 8 > 1 ? W / 8 : 1;                  // _adapthist.py:78-79
+    j.sy = j.kh / 2; j.sx = j.kw / 2;                                             // :123
+    const int ey = (j.kh - H % j.kh) % j.kh + (j.kh + 1) / 2, ex = (j.kw - W % j.kw) % j.kw + (j.kw + 1) / 2;   // :125-126
+    j.nty = (j.sy + H + ey) / j.kh - 1; j.ntx = (j.sx + W + ex) / j.kw - 1;       // :141
+    if (j.nty < 1 || j.ntx < 1) return fail(LFA_ERR_UNSUPPORTED, "image %dx%d too small for CLAHE tiles", H, W);
+    {
+        const double c = 0.05 * (double)((long long)j.kh * j.kw);                // :155
+        j.clim = c < 1.0 ? 1 : (int)c;
+    }
+    j.cap = max_boxes;
+    j.w0 = w3[1]; j.w1 = w3[0];
+    const size_t N = (size_t)n, npix = (size_t)H * W;
+    if ((rc = ensure(h->ln_g, N * npix * 8)) || (rc = ensure(h->ln_u, N * npix * 2)) || (rc = ensure(h->ln_binlut, N * 65536)) ||
+        (rc = ensure(h->ln_maps, N * (size_t)j.nty * j.ntx * 256 * 4)) || (rc = ensure(h->ln_levels, N * npix * 2)) ||
+        (rc = ensure(h->ln_lhist, N * 16384 * 4)) || (rc = ensure(h->ln_lval, N * 16384 * 8)) || (rc = ensure(h->ln_cls, N * 16384 * 2)) ||
+        (rc = ensure(h->ln_parent, N * npix * 4)) || (rc = ensure(h->ln_bbox, N * npix * 16)) ||
+        (rc = ensure(h->ln_cand, N * (size_t)j.cap * 12)) || (rc = ensure(h->ln_info, N * sizeof(LfaLinesInfo))))
+        return rc;
+    j.g = (const double*)h->ln_g.p; j.u = (uint16_t*)h->ln_u.p; j.binlut = (uint8_t*)h->ln_binlut.p; j.maps = (int32_t*)h->ln_maps.p;
+    j.levels = (uint16_t*)h->ln_levels.p; j.lhist = (uint32_t*)h->ln_lhist.p; j.lval = (double*)h->ln_lval.p; j.cls = (uint16_t*)h->ln_cls.p;
+    j.parent = (int32_t*)h->ln_parent.p; j.bbox = (int32_t*)h->ln_bbox.p; j.cand = (int32_t*)h->ln_cand.p; j.info = (LfaLinesInfo*)h->ln_info.p;
+    lfa::Job gj{};
+    gj.images = (const uint8_t*)images;
+    gj.img_bytes = (int64_t)H * W * (dtype == LFA_U16 ? 2 : 1);
+    gj.n = n; gj.H = H; gj.W = W; gj.C = 1; gj.dtype = dtype;
+    gj.aligned16 = (((uintptr_t)images & 15) == 0 && (gj.img_bytes & 15) == 0) ? 1 : 0;
+    if (h->have_done && s != h->last_stream) LFA_HIP(hipStreamWaitEvent(s, h->done_event, 0));
+    TimerScope ts(h);
+    LFA_HIP(lfa::launch_gaussian_w(gj, w9, 4, h->ln_g.p, 0, s));                 // detection.py:166
+    LFA_HIP(lfa::launch_lines(j, out_boxes, out_counts, max_boxes, s));
+    if (out_info) LFA_HIP(hipMemcpyAsync(out_info, j.info, N * sizeof(LfaLinesInfo), hipMemcpyDeviceToDevice, s));
+    LFA_HIP(hipEventRecord(h->done_event, s));
+    h->last_stream = s; h->have_done = true;
+    h->lines_last = j; h->have_lines = true;
+    return LFA_OK;
+}
+
+int lfa_lines_debug_fetch(LfaHandle h, int image_index, int what, void* out, int64_t out_bytes, void* stream) {
+    if (!h || !out) return fail(LFA_ERR_ARG, "null argument");
+    if (!h->have_lines) return fail(LFA_ERR_ARG, "no lfa_detect_lines_batch call has run on this handle yet");
+    const lfa::LinesJob& j = h->lines_last;
+    if (image_index < 0 || image_index >= j.n) return fail(LFA_ERR_ARG, "image_index %d outside the last batch of %d", image_index, j.n);
+    const int64_t npix = (int64_t)j.H * j.W;
+    const void* src = nullptr;
+    int64_t bytes = 0;
+    switch (what) {
+        case LFA_LDBG_GAUSS:  src = j.g + image_index * npix; bytes = npix * 8; break;
+        case LFA_LDBG_U16:    src = j.u + image_index * npix; bytes = npix * 2; break;
+        case LFA_LDBG_LEVELS: src = j.levels + image_index * npix; bytes = npix * 2; break;
+        case LFA_LDBG_ROOTS:  src = j.parent + image_index * npix; bytes = npix * 4; break;
+        case LFA_LDBG_LVAL:   src = j.lval + (int64_t)image_index * 16384; bytes = 16384 * 8; break;
+        default: return fail(LFA_ERR_ARG, "lfa_lines_debug_fetch: unknown item %d", what);
+    }
+    if (out_bytes < bytes) return fail(LFA_ERR_ARG, "lfa_lines_debug_fetch(what=%d) needs %lld bytes, got %lld", what, (long long)bytes, (long long)out_bytes);
+    LFA_ON_DEVICE(h->device);
+    LFA_HIP(hipMemcpyAsync(out, src, (size_t)bytes, hipMemcpyDefault, (hipStream_t)stream));
     return LFA_OK;
 }
 

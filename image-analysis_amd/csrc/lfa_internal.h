@@ -129,5 +129,29 @@ hipError_t launch_gaussian_w(const Job& j, const double* w, int radius, void* ou
 constexpr int kGaussMaxRadius = 8;
 hipError_t launch_debug(const Job& j, int image, int what, void* out, int64_t out_bytes, hipStream_t s);
 
+// detect_lines (k_lines.hip): one batch call, passed by value
+struct LinesJob {
+    int32_t n, H, W;
+    int32_t kh, kw;          // CLAHE tile: max(H // 8, 1) x max(W // 8, 1)
+    int32_t sy, sx;          // rows / columns padded in front: kh // 2, kw // 2
+    int32_t nty, ntx;        // tiles with a histogram: padded size / tile - 1
+    int32_t clim;            // clip limit in counts: int(clip(0.05 * kh * kw, 1, None))
+    int32_t cap;             // candidate boxes kept per image
+    double w0, w1;           // centre and side tap of the 3-tap Gaussian of threshold_local
+    const double* g;         // [n][H*W]     gaussian(image)
+    uint16_t* u;             // [n][H*W]     img_as_uint of the gamma-adjusted image
+    uint8_t* binlut;         // [n][65536]   uint16 value -> CLAHE bin
+    int32_t* maps;           // [n][nty*ntx][256] tile mappings
+    uint16_t* levels;        // [n][H*W]     _clahe's result
+    uint32_t* lhist;         // [n][16384]   histogram of levels, then its inclusive prefix
+    double* lval;            // [n][16384]   final float value per level
+    uint16_t* cls;           // [n][16384]   class per level (0 = background)
+    int32_t* parent;         // [n][H*W]     union-find over pixels
+    int32_t* bbox;           // [n][H*W][4]  minr, minc, maxr, maxc at roots
+    int32_t* cand;           // [n][cap][3]  root, minr, maxr of the boxes that pass the filter
+    LfaLinesInfo* info;      // [n]
+};
+hipError_t launch_lines(const LinesJob& j, LfaLineBox* out, int32_t* counts, int max_boxes, hipStream_t s);
+
 }  // namespace lfa
 #endif

@@ -93,9 +93,22 @@ def remove_outliers(lst):
 
 
 def detect_lines(image) -> list:
-    """detection.py:156-201 is never called by the reference; only its Gaussian stage is built
-    (see `gaussian`)."""
-    raise NotImplementedError("detect_lines is dead code in the reference; only its gaussian stage is implemented")
+    """detection.py:156-201 -> [[minr, maxr, minc, maxc], ...] (the reference defines this function and never calls it).
+
+    Gaussian, local threshold, gamma 0.5, CLAHE, percentile rescale, labelling of equal values and the box filter all run
+    on the device (`lfa_detect_lines_batch`); the matplotlib figure of :162-164 is not drawn.  Like the reference it needs
+    a 2-D image: on colour input the reference fails at `minr, minc, maxr, maxc = region.bbox` (:189)."""
+    image = np.asanyarray(image)
+    if image.ndim != 2:
+        raise ValueError("too many values to unpack (expected 4)" if image.ndim > 2 else "detect_lines needs a 2-D image")
+    if image.size == 0:
+        raise ValueError("empty image")
+    _check_pixels(image)
+    boxes, info = _engine(image.shape[0], image.shape[1]).detect_lines(image[None])
+    if info["status"][0] & 2:
+        # skimage.util.dtype._convert inside equalize_adapthist (_adapthist.py:73)
+        raise ValueError("Images of type float must be between -1 and 1.")
+    return [[int(b["minr"]), int(b["maxr"]), int(b["minc"]), int(b["maxc"])] for b in boxes[0]]
 
 
 def gaussian(image, sigma=1):

@@ -79,3 +79,26 @@ def synth_rois(n_images, H, W, per_image=256, seed=99) -> np.ndarray:
     out["image"] = np.repeat(np.arange(n_images), per_image)
     out["r0"], out["r1"], out["c0"], out["c1"] = r0, r0 + h, c0, c0 + w
     return out
+
+
+def synth_lines(H=384, W=512, seed=1234, dtype=np.uint8, n_lines=2) -> np.ndarray:
+    """(H,W) uint8 / uint16 strip-like crop for detect_lines: noisy mid-grey body with a slow gradient and `n_lines` thin,
+    slightly tilted, saturated transverse lines.  The function keeps components of EQUAL value after a percentile rescale
+    that sets the top 1 % of the pixels to 1.0, whose bounding box is wider than tall and covers 0.65 % - 4 % of the image:
+    thin tilted lines (few pixels, tall enough box) are what passes."""
+    rng = np.random.default_rng(seed)
+    y = np.arange(H)[:, None]
+    x = np.arange(W)[None, :]
+    img = 90 + 25 * np.sin(y / H * 3.1) + 10 * (x / W) + rng.normal(0, 5, size=(H, W))
+    need = int(np.ceil(0.0065 * H)) + 1                       # rows a full-width box needs to pass min_area
+    for b in range(n_lines):
+        r0 = int((0.1 + 0.8 * (b + rng.uniform(0.3, 0.7)) / n_lines) * H)
+        c0, c1 = int(rng.uniform(0.0, 0.04) * W), int(rng.uniform(0.96, 1.0) * W)
+        tilt = need + int(rng.integers(0, 3))
+        cols = np.arange(c0, c1)
+        rows = np.clip(r0 + (cols - c0) * tilt // max(1, c1 - c0), 0, H - 1)
+        img[rows, cols] = 255
+    img = np.clip(img, 0, 255)
+    if np.dtype(dtype) == np.uint16:
+        return (img.astype(np.uint16) * 257)
+    return img.astype(np.uint8)

@@ -240,6 +240,44 @@ int64_t lfa_static_workspace_bytes(void);
 int lfa_gaussian_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W, int C,
                        double sigma, const double* host_weights, int radius, void* out, int out_f32, void* stream);
 
+/* ---- detect_lines: LFA-Image_Analysis/detection.py:156-201 (defined by the reference, never called) ------ */
+
+typedef struct {
+    int32_t minr, maxr, minc, maxc;   /* [minr, maxr, minc, maxc] as detection.py:200 appends them (minc = 0, maxc = W always) */
+} LfaLineBox;
+
+typedef struct {
+    int32_t umin, umax;               /* extremes of the uint16 image img_as_uint makes inside equalize_adapthist (_adapthist.py:73) */
+    int32_t cmin, cmax;               /* extremes of _clahe's uint16 result (_adapthist.py:87) */
+    double p80, p99;                  /* np.percentile(enhanced_image, (80, 99)), detection.py:179 */
+    int32_t n_labels;                 /* labeled_image.max(), detection.py:184 */
+    int32_t n_boxes;                  /* regions that pass the filter of detection.py:191-199 (may exceed max_boxes) */
+    int32_t status;                   /* bit 0: more boxes than max_boxes; bit 1: a value above 1 reached img_as_uint (the
+                                         reference raises "Images of type float must be between -1 and 1.") */
+    int32_t pad;
+} LfaLinesInfo;
+
+/* = for image in batch: detect_lines(image) for 2-D uint8 / uint16 images (C == 1; the reference's function fails on
+ *   colour input at its `minr, minc, maxr, maxc = region.bbox`).  Stages: gaussian(sigma 1) -> threshold_local(block 3,
+ *   'gaussian') -> image * (threshold > 0) -> adjust_gamma(0.5) -> equalize_adapthist(clip_limit 0.05) -> percentile
+ *   rescale (80, 99) -> label (equal values, 8-connected) -> bounding boxes -> area / shape filter, all on the device.
+ * w_sigma1: HOST, 9 taps of scipy's Gaussian kernel for sigma 1; w_local: HOST, 3 taps for sigma (3-1)/6; NULL = computed
+ *   here with the C library's exp().
+ * out_boxes: device, n*max_boxes, in the order the reference appends them; out_counts: device, n; out_info: device, n, or NULL.
+ * The workspace of this path (about 31 bytes per pixel) is allocated by the first call that needs it and grows with later
+ * ones: unlike detect/analyze, this call MAY allocate (and then waits for the device). */
+int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W,
+                           const double* w_sigma1, const double* w_local,
+                           LfaLineBox* out_boxes, int max_boxes, int32_t* out_counts, LfaLinesInfo* out_info, void* stream);
+
+#define LFA_LDBG_GAUSS   0   /* float64 H*W : sk.filters.gaussian(image)                        (detection.py:166) */
+#define LFA_LDBG_U16     1   /* uint16  H*W : img_as_uint(adjust_gamma(...)) inside equalize_adapthist (_adapthist.py:73) */
+#define LFA_LDBG_LEVELS  2   /* uint16  H*W : _clahe's result                                   (_adapthist.py:87) */
+#define LFA_LDBG_ROOTS   3   /* int32   H*W : index of the first pixel of the pixel's component, -1 = background (detection.py:184) */
+#define LFA_LDBG_LVAL    4   /* float64 16384 : value of rescale_intensity(enhanced_image, ...) per level (detection.py:180) */
+/* Copy intermediate `what` of image `image_index` of the handle's last lfa_detect_lines_batch call to `out` (device or host). */
+int lfa_lines_debug_fetch(LfaHandle h, int image_index, int what, void* out, int64_t out_bytes, void* stream);
+
 /* ---- diagnostics for parity tests (valid until the next detect/analyze call on this handle) ----------------------- */
 
 #define LFA_DBG_MASK    0   /* uint8 H*W : image_copy > threshold            (detection.py:39,47) */

@@ -403,7 +403,58 @@ def write_skimage_fixtures():
     print("skimage fixtures:", len(names), "detect cases;", k, "point-op tables;", g, "gaussian images")
 
 
+def detect_lines_cases():
+    """(name, 2-D image) -- small inputs for detect_lines (detection.py:156-201)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from image_analysis_amd.synth import synth_lines
+    rng = np.random.default_rng(77)
+    flat = rng.integers(80, 90, size=(72, 88)).astype(np.uint16) * 300
+    flat[20:50, 10:70] = 40000
+
+    def tiny(seed, H=17, W=23):                      # tiny frames: many components pass the box filter
+        r = np.random.default_rng(seed)
+        img = r.normal(90, 12, (H, W))
+        img[H // 5:H // 5 + max(1, H // 10), W // 10:W - W // 10] += 80
+        img[H // 2:H // 2 + H // 8, W // 8:W - W // 4] += 50
+        return np.clip(img, 0, 255).astype(np.uint8)
+    return [("lines_96x128_u8", synth_lines(96, 128, 1, np.uint8)),
+            ("lines_131x77_u16", synth_lines(131, 77, 2, np.uint16)),
+            ("lines_200x264_u8", synth_lines(200, 264, 3, np.uint8)),
+            ("lines_384x512_u8", synth_lines(384, 512, 4, np.uint8)),
+            ("tiny_seed2", tiny(2)), ("tiny_seed7", tiny(7)), ("tiny_seed23", tiny(23)),
+            ("noise_64x64_u8", rng.integers(0, 256, size=(64, 64), dtype=np.uint8)),
+            ("noise_17x23_u8", rng.integers(0, 256, size=(17, 23), dtype=np.uint8)),
+            ("noise_9x8_u8", rng.integers(0, 256, size=(9, 8), dtype=np.uint8)),
+            ("constant_40x56_u8", np.full((40, 56), 77, np.uint8)),
+            ("zeros_33x47_u8", np.zeros((33, 47), np.uint8)),
+            ("plateau_72x88_u16", flat),
+            ("dark_50x61_u16", rng.integers(0, 40, size=(50, 61)).astype(np.uint16))]
+
+
+def write_detect_lines_fixtures():
+    """The reference's detect_lines (detection.py:156-201) run over the vendored skimage sources up to its label() call
+    (Cython): every intermediate as SHA-256, the percentiles and the image handed to label() as arrays."""
+    import vendored_skimage as V
+    warnings.simplefilter("ignore")
+    run = V.reference_detect_lines()
+    out, names = {}, []
+    for name, im in detect_lines_cases():
+        t = run(im)
+        names.append(name)
+        out[f"{name}__image"] = im
+        for k in ("gauss", "local", "gamma", "enhanced"):
+            out[f"{name}__{k}_sha"] = sha(t[k])
+        out[f"{name}__percentiles"] = np.asarray(t["percentiles"], dtype=np.float64)
+        out[f"{name}__label_input"] = np.asarray(t["label_input"], dtype=np.float64)
+        assert np.array_equal(t["label_input"], t["rescaled"])
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "ref_detect_lines.npz"), **out)
+    print("detect_lines fixtures:", len(names), "cases")
+
+
 if __name__ == "__main__":
+    if "--only-lines" in sys.argv:
+        sys.exit(write_detect_lines_fixtures())
     if "--only-samples" in sys.argv:
         sys.exit(write_real_samples())
     if "--only-skimage" in sys.argv:

@@ -16,6 +16,7 @@ have bound:
     SP/skimage/filters/thresholding.py (three functions)      _validate_image_histogram, threshold_otsu, threshold_local
     SP/skimage/morphology/misc.py, footprints.py (rectangle), binary.py      binary_erosion / binary_dilation / rectangle
     SP/skimage/measure/_label.py, _regionprops.py             label, regionprops (bbox, area)
+    SP/skimage/exposure/_adapthist.py                         equalize_adapthist (detect_lines only)
 
 Three names that numpy 2 removed are given back with their numpy-1.24 meaning (the vendored numpy is 1.24.3):
 `np.float_` (= float64), `np.product` (= prod), `np.obj2sctype` (scalar type of a dtype-like).  Names bound by imports
@@ -142,9 +143,14 @@ def skimage():
     rp = load("measure/_regionprops.py", dict(std, warn=warnings.warn, pdist=scipy.spatial.distance.pdist, _moments=None,
                                               find_contours=None, marching_cubes=None, euler_number=None, perimeter=None,
                                               perimeter_crofton=None))
+    # equalize_adapthist: its decorator adapt_rgb(hsv_value) passes a non-colour image straight through (color/adapt_rgb.py)
+    adapt = load("exposure/_adapthist.py", dict(std, numbers=numbers, _supported_float_type=utils._supported_float_type,
+                                                adapt_rgb=lambda _f: (lambda fn: fn), hsv_value=None,
+                                                rescale_intensity=exposure.rescale_intensity, img_as_uint=dtype.img_as_uint))
     S = types.SimpleNamespace
     return S(exposure=S(adjust_gamma=exposure.adjust_gamma, histogram=exposure.histogram,
-                        rescale_intensity=exposure.rescale_intensity),
+                        rescale_intensity=exposure.rescale_intensity, equalize_adapthist=adapt.equalize_adapthist,
+                        _clahe=adapt._clahe),
              color=S(rgb2gray=color.rgb2gray),
              filters=S(threshold_otsu=thresholding.threshold_otsu, threshold_local=thresholding.threshold_local,
                        gaussian=sfilters.gaussian),
@@ -190,3 +196,53 @@ def reference_detect(min_maxr, min_maxc, angle_threshold=10):
         exec(compile("\n" * (lo - 1) + "\n".join(src[lo - 1:hi]), "/root/reference/LFA-Image_Analysis/detection.py", "exec"), ns)
     ns["trace"] = trace
     return ns["detect_lateral_flow_tests"], ns
+
+
+class StopAtLabel(Exception):
+    pass
+
+
+def reference_detect_lines():
+    """detect_lines as LFA-Image_Analysis/detection.py:156-201 defines it, bound to the vendored skimage, up to its call of
+    sk.measure.label (:184): label() of a non-boolean image is Cython (`_ccomp`, a darwin binary), so the run stops there
+    and hands back every intermediate the function passed through the skimage / numpy calls.  The matplotlib calls of
+    :162-164 (a figure that shows the input) are bound to no-ops.  Returns run(image) -> trace dict."""
+    sk = skimage()
+    S = types.SimpleNamespace
+
+    def run(image):
+        trace = {}
+
+        def rec(name, fn):
+            def wrapped(*a, **k):
+                out = fn(*a, **k)
+                trace[name] = out
+                return out
+            return wrapped
+
+        def stop(img):
+            trace["label_input"] = img
+            raise StopAtLabel()
+
+        class NP(types.ModuleType):
+            def __getattr__(self, name):
+                return getattr(numpy, name)
+        npx = NP("numpy")
+        npx.percentile = rec("percentiles", numpy.percentile)
+        fig = S(add_subplot=lambda *a, **k: None)
+        ns = {"np": npx, "plt": S(figure=lambda **k: fig, imshow=lambda *a, **k: None),
+              "sk": S(filters=S(gaussian=rec("gauss", sk.filters.gaussian), threshold_local=rec("local", sk.filters.threshold_local)),
+                      exposure=S(adjust_gamma=rec("gamma", sk.exposure.adjust_gamma),
+                                 equalize_adapthist=rec("enhanced", sk.exposure.equalize_adapthist),
+                                 rescale_intensity=rec("rescaled", sk.exposure.rescale_intensity)),
+                      measure=S(label=stop)),
+              "regionprops": None}
+        src = open("/root/reference/LFA-Image_Analysis/detection.py").read().split("\n")
+        lo, hi = 156, 201
+        exec(compile("\n" * (lo - 1) + "\n".join(src[lo - 1:hi]), "/root/reference/LFA-Image_Analysis/detection.py", "exec"), ns)
+        try:
+            ns["detect_lines"](image)
+        except StopAtLabel:
+            pass
+        return trace
+    return run

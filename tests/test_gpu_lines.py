@@ -1,0 +1,125 @@
+"""detect_lines (detection.py:156-201) on the GPU, through the C ABI (lfa_detect_lines_batch).
+
+* against tests/golden/ref_detect_lines.npz -- the reference's own lines run over its vendored scikit-image sources up to
+  label() -- with no oracle in between: percentile bits and the float image handed to label(), rebuilt here from the
+  device's level image and its per-level value table;
+* against oracle/lines_oracle.py on larger and odd-shaped images, every stage bit for bit: Gaussian, img_as_uint image,
+  CLAHE levels, percentiles, label image (from the device's component roots), label count and the returned boxes;
+* through the drop-in module, including its exceptions."""
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(GOLDEN, "ref_detect_lines.npz"))
+NAMES = [str(n) for n in G["names"]]
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import image_analysis_amd._capi as capi
+    return capi
+
+
+@pytest.fixture(scope="module")
+def eng(capi):
+    e = capi.Engine(device=0, max_h=1536, max_w=2048, max_c=1, max_batch=4)
+    yield e
+    e.close()
+
+
+def labels_from_roots(roots):
+    """label image (raster order of first pixel) from the per-pixel root indices the device keeps (-1 = background)"""
+    r = roots.ravel()
+    fg = r >= 0
+    ids = np.unique(r[fg])
+    assert np.array_equal(r[ids], ids)                      # every root is its own root and the smallest index of its component
+    out = np.zeros(r.size, np.int64)
+    out[fg] = np.searchsorted(ids, r[fg]) + 1
+    return out.reshape(roots.shape)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_equals_the_reference_run(capi, eng, name):
+    im = G[f"{name}__image"]
+    H, W = im.shape
+    boxes, info = eng.detect_lines(im[None])
+    inf = info[0]
+    assert np.array_equal(np.array([inf["p80"], inf["p99"]]).view(np.uint64), G[f"{name}__percentiles"].view(np.uint64))
+    levels = eng.lines_debug(0, capi.LDBG_LEVELS, H, W)
+    lval = eng.lines_debug(0, capi.LDBG_LVAL, H, W)
+    assert np.array_equal(lval[levels].view(np.uint64), G[f"{name}__label_input"].view(np.uint64))
+
+
+def _against_oracle(capi, eng, im):
+    from oracle import lines_oracle as L
+    H, W = im.shape
+    d = L.lines_debug(im)
+    boxes, info = eng.detect_lines(im[None])
+    inf = info[0]
+    assert np.array_equal(eng.lines_debug(0, capi.LDBG_GAUSS, H, W).view(np.uint64), d["gauss"].view(np.uint64))
+    assert np.array_equal(eng.lines_debug(0, capi.LDBG_U16, H, W), d["u16"])
+    assert (int(inf["umin"]), int(inf["umax"])) == (int(d["u16"].min()), int(d["u16"].max()))
+    assert np.array_equal(eng.lines_debug(0, capi.LDBG_LEVELS, H, W), d["levels"])
+    assert (int(inf["cmin"]), int(inf["cmax"])) == (int(d["levels"].min()), int(d["levels"].max()))
+    assert np.float64(inf["p80"]).tobytes() == np.float64(d["p80"]).tobytes()
+    assert np.float64(inf["p99"]).tobytes() == np.float64(d["p99"]).tobytes()
+    lab = labels_from_roots(eng.lines_debug(0, capi.LDBG_ROOTS, H, W))
+    assert np.array_equal(lab, d["labels"])
+    assert int(inf["n_labels"]) == int(d["labels"].max())
+    got = [[int(b["minr"]), int(b["maxr"]), int(b["minc"]), int(b["maxc"])] for b in boxes[0]]
+    assert got == d["strips"]
+    assert int(inf["n_boxes"]) == len(d["strips"]) and int(inf["status"]) == 0
+    return d
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_equals_oracle_on_the_fixture_images(capi, eng, name):
+    _against_oracle(capi, eng, G[f"{name}__image"])
+
+
+@pytest.mark.parametrize("shape,dtype,seed", [((384, 512), np.uint8, 4), ((768, 1024), np.uint16, 5), ((301, 517), np.uint8, 6),
+                                              ((1536, 2048), np.uint8, 7), ((8, 8), np.uint8, 8), ((2, 3), np.uint8, 9)])
+def test_hip_equals_oracle_on_larger_and_odd_frames(capi, eng, shape, dtype, seed):
+    from image_analysis_amd.synth import synth_lines
+    if min(shape) >= 64:
+        im = synth_lines(shape[0], shape[1], seed, dtype)
+    else:
+        im = np.random.default_rng(seed).integers(0, 256, size=shape).astype(dtype)
+    d = _against_oracle(capi, eng, im)
+    if shape == (384, 512):
+        assert d["strips"] == [[100, 107, 0, 512], [293, 300, 0, 512]]
+
+
+def test_batch_of_different_images_and_box_overflow(capi, eng):
+    from oracle import lines_oracle as L
+    ims = np.stack([G["tiny_seed2__image"], G["tiny_seed7__image"], G["tiny_seed23__image"]])
+    want = [L.detect_lines(im) for im in ims]
+    boxes, info = eng.detect_lines(ims)
+    got = [[[int(b["minr"]), int(b["maxr"]), int(b["minc"]), int(b["maxc"])] for b in bx] for bx in boxes]
+    assert got == want
+    boxes, info = eng.detect_lines(ims, max_boxes=2)              # more boxes than slots: the binding asks again with more
+    got = [[[int(b["minr"]), int(b["maxr"]), int(b["minc"]), int(b["maxc"])] for b in bx] for bx in boxes]
+    assert got == want
+
+
+def test_drop_in_detect_lines(capi):
+    import image_analysis_amd.detection as detection
+    from oracle import lines_oracle as L
+    im = G["lines_200x264_u8__image"]
+    assert detection.detect_lines(im) == L.detect_lines(im) == [[51, 55, 0, 264]]
+    with pytest.raises(ValueError):
+        detection.detect_lines(np.zeros((8, 8, 3), np.uint8))
+    # a saturated frame: the Gaussian of all-ones exceeds 1 by rounding and img_as_uint refuses it, here as in the reference
+    sat = np.full((32, 32), 255, np.uint8)
+    try:
+        want = L.detect_lines(sat)
+    except ValueError as e:
+        with pytest.raises(ValueError, match=str(e)[:20]):
+            detection.detect_lines(sat)
+    else:
+        assert detection.detect_lines(sat) == want
