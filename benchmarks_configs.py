@@ -3,7 +3,7 @@
 select-region ROIs), photo-like content and the Gaussian stage, each with per-kernel HIP-event times and GB/s against
 its algorithmic bytes.  bench.py runs `secondary()` after its headline timed region and puts the
 results into the "configs" object of its JSON line, so they are on the driver's clock; by hand:
-    python benchmarks_configs.py [u16|u16real|big|photo|rois|gauss|peaks|stream] ..."""
+    python benchmarks_configs.py [u16|u16real|big|photo|rois|gauss|peaks|lines|stream] ..."""
 import ctypes as C
 import importlib
 import json
@@ -250,6 +250,33 @@ def bench_gauss(B=64, steps=10):
     return outs
 
 
+def bench_lines(B=16, steps=5, H=1536, W=2048):
+    """detect_lines over a batch of 2-D uint8 frames; bytes = the frames read once."""
+    pool_np = np.stack([synth.synth_lines(H, W, 100 + i, np.uint8) for i in range(4)])
+    p = torch.from_numpy(pool_np.reshape(4, -1)).to(DEV())
+    batch = p[torch.arange(B, device=DEV()) % 4].contiguous()
+    eng = capi.Engine(device=DEV().index, max_h=H, max_w=W, max_c=1, max_batch=B)
+    cap = 256
+    boxes = capi.dev_bytes(B * cap * 16, DEV()); counts = torch.zeros(B, dtype=torch.int32, device=DEV())
+    info = capi.dev_bytes(B * capi.LINESINFO_DT.itemsize, DEV())
+    w9, w3 = eng.scipy_gaussian_taps(1.0, 4), eng.scipy_gaussian_taps(2 / 6.0, 1)
+    st = capi.current_stream_ptr(DEV())
+
+    def step():
+        capi._check(capi.lib.lfa_detect_lines_batch(eng._h, batch.data_ptr(), capi.LFA_U8, B, H, W, w9.ctypes.data, w3.ctypes.data,
+                                                    boxes.data_ptr(), cap, counts.data_ptr(), info.data_ptr(), st))
+    dt = timed(step, steps)
+    eng.timing("*"); step(); torch.cuda.synchronize(); kt = eng.timing_read(); eng.timing(None)
+    inf = capi.from_device(info, capi.LINESINFO_DT, B)
+    byts = B * H * W
+    out = {"config": f"detect_lines: {B} frames {H}x{W} uint8 (synth_lines)", "frames": B, "steps": steps,
+           "ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(B / dt, 1), "labels_mean": float(inf["n_labels"].mean()),
+           "boxes_mean": float(inf["n_boxes"].mean()), "algorithmic_bytes_per_step": byts,
+           "e2e_frac_hbm": round(byts / dt / (HBM_PEAK_GBS * 1e9), 5), "kernel_ms": _kernel_table(kt, top=12)}
+    eng.close()
+    return out
+
+
 def bench_peaks(n=16384, length=288):
     rng = np.random.default_rng(0)
     x = np.arange(length)
@@ -317,6 +344,8 @@ def named(name, steps=10):
         return {"gaussian_rgb_u8_f64": g[0], "gaussian_u16_f64": g[1], "gaussian_rgb_u8_f32": g[2]}
     if name == "photo":
         return {"photo_like_1536x2048x3": bench_photo(steps=steps)}
+    if name == "lines":
+        return {"detect_lines_1536x2048_u8": bench_lines(steps=min(steps, 5))}
     raise ValueError(name)
 
 
@@ -338,4 +367,5 @@ if __name__ == "__main__":
     if "rois" in what: show(bench_rois())
     if "gauss" in what: show(bench_gauss())
     if "peaks" in what: show(bench_peaks())
+    if "lines" in what: show(bench_lines())
     if "stream" in what: show(bench_stream())

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_lines_local(LinesJob j) {
     int lo = 65535, hi = 0;
     int over = 0;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        const int y = (int)(p / j.W), x = (int)(p - (int64_t)y * j.W);
+        const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
         const int ym = reflect_half(y - 1, j.H), yp = reflect_half(y + 1, j.H);
         const int xm = reflect_half(x - 1, j.W), xp = reflect_half(x + 1, j.W);
         auto col = [&](int xx) -> double {                            // axis 0 first (scipy.ndimage.gaussian_filter)
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_clahe_blend(LinesJob j) {
     uint16_t* lv = j.levels + (int64_t)img * npix;
     int lo = 65535, hi = 0;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        const int y = (int)(p / j.W), x = (int)(p - (int64_t)y * j.W);
+        const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
         const int py = y + j.sy, px = x + j.sx;
         const int by = py / j.kh, bx = px / j.kw;
         const double cy = (double)(py % j.kh) / (double)j.kh, cx = (double)(px % j.kw) / (double)j.kw;
@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void k_ccl_init(LinesJob j) {
     int4* bbox = (int4*)(j.bbox + (int64_t)img * npix * 4);
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
         parent[p] = (int)p;
-        bbox[p] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
+        const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
+        bbox[p] = make_int4(y, x, y + 1, x + 1);                         // a root starts from its own pixel; the others add theirs
     }
 }
 
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void k_ccl_merge(LinesJob j) {
     const uint16_t* cls = j.cls + (int64_t)img * 16384;
     int32_t* parent = j.parent + (int64_t)img * npix;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        const int y = (int)(p / j.W), x = (int)(p - (int64_t)y * j.W);
+        const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
         const uint16_t c = cls[lv[p] & 16383];
         if (!c) continue;
         if (x > 0 && cls[lv[p - 1] & 16383] == c) ccl_union(parent, (int)p, (int)p - 1);
@@ -343,8 +344,9 @@ __global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
         if (!cls[lv[p] & 16383]) { parent[p] = -1; continue; }           // background
         const int r = ccl_find(parent, (int)p);
-        parent[p] = r;                                                   // (a root keeps itself; others only ever point to smaller indices)
-        const int y = (int)(p / j.W), x = (int)(p - (int64_t)y * j.W);
+        if (r == (int)p) continue;                                       // most components of a CLAHE'd frame are single pixels
+        parent[p] = r;                                                   // (others only ever point to smaller indices)
+        const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
         atomicMin(&bbox[4 * (int64_t)r + 0], y); atomicMin(&bbox[4 * (int64_t)r + 1], x);
         atomicMax(&bbox[4 * (int64_t)r + 2], y + 1); atomicMax(&bbox[4 * (int64_t)r + 3], x + 1);
     }
