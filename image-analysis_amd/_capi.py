@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LFA_LIB_PATH") or os.path.join(_HERE, "liblfa_hip.so")     # LFA_LIB_PATH: an experimental build (tools/)
 
 LFA_U8, LFA_U16 = 0, 1
+ELEM_CODES = {"uint8": 0, "uint16": 1, "int8": 2, "int16": 3, "int32": 4, "uint32": 5, "float64": 6}   # lfa.h LFA_E_*
 DBG_MASK, DBG_OPENED, DBG_LABELS, DBG_TABLE, DBG_HIST, DBG_PLANE, DBG_ONEPASS = 0, 1, 2, 3, 4, 5, 6
 GRAY_NVARIANTS = 6
 
@@ -65,6 +66,7 @@ def _load():
     lib.lfa_profile_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp]
     lib.lfa_profile_lut_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, vp, vp]
     lib.lfa_peaks_batch.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.lfa_profile_any_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp]
     lib.lfa_analyze_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.lfa_analyze_batch_static.argtypes = lib.lfa_analyze_batch.argtypes
     lib.lfa_reserve.argtypes = [vp, i32, i32]
@@ -83,7 +85,7 @@ def _load():
     for name in ("lfa_timing_enable", "lfa_timing_read","lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant", "lfa_detect_batch",
                  "lfa_profile_batch", "lfa_profile_lut_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch",
                  "lfa_debug_fetch", "lfa_sync", "lfa_stream_wait_passes", "lfa_chain_passes", "lfa_analyze_batch_static", "lfa_reserve",
-                 "lfa_detect_lines_batch", "lfa_lines_debug_fetch"):
+                 "lfa_detect_lines_batch", "lfa_lines_debug_fetch", "lfa_profile_any_batch"):
         getattr(lib, name).restype = i32
     return lib
 
@@ -95,7 +97,8 @@ EXPORTED = ("lfa_version", "lfa_last_error", "lfa_create", "lfa_destroy", "lfa_s
             "lfa_detect_batch", "lfa_profile_batch", "lfa_profile_lut_batch", "lfa_peaks_batch", "lfa_analyze_batch",
             "lfa_gaussian_batch", "lfa_debug_fetch", "lfa_sync", "lfa_timing_enable", "lfa_timing_read",
             "lfa_stream_wait_passes", "lfa_chain_passes", "lfa_analyze_batch_static", "lfa_static_workspace_bytes", "lfa_reserve",
-            "lfa_workspace_bytes", "lfa_detect_lines_batch", "lfa_lines_debug_fetch")
+            "lfa_workspace_bytes", "lfa_detect_lines_batch", "lfa_lines_debug_fetch",
+            "lfa_profile_any_batch")
 
 
 def _check(rc):
@@ -444,6 +447,31 @@ class Engine:
             raise LfaError(-1, f"ROI {int(np.flatnonzero(pk['n_peaks'] < 0)[0])} was rejected by the device")
         pr = profiles.cpu().numpy().reshape(n_rois, stride)
         return [pr[i, :(max(0, pk[i]["length"]) if pk[i]["n_peaks"] >= 0 else 0)].copy() for i in range(n_rois)], pk.copy()
+
+    def profiles_any(self, regions: np.ndarray, rois: np.ndarray, inverse=False, rng=15):
+        """Engine.profiles for regions of the other element types np.nanmean takes (lfa_profile_any_batch): (n,H,W[,C])
+        int8 / int16 / int32 / uint32 / float64."""
+        torch = _torch()
+        regions = np.asarray(regions)
+        if regions.ndim == 3:
+            n, H, W = regions.shape
+            Cc = 1
+        else:
+            n, H, W, Cc = regions.shape
+        code = ELEM_CODES[regions.dtype.name]
+        rois = np.ascontiguousarray(rois, dtype=ROI_DT)
+        n_rois = len(rois)
+        stride = max(1, int((rois["r1"] - rois["r0"]).max()))
+        t, rt = to_device(regions, self.device), to_device(rois, self.device)
+        profiles = torch.zeros(n_rois * stride, dtype=torch.float64, device=self.device)
+        peaks = dev_bytes(n_rois * PEAKS_DT.itemsize, self.device)
+        _check(lib.lfa_profile_any_batch(self._h, t.data_ptr(), code, n, H, W, Cc, rt.data_ptr(), n_rois, int(bool(inverse)), int(rng),
+                                         profiles.data_ptr(), stride, peaks.data_ptr(), current_stream_ptr(self.device)))
+        pk = from_device(peaks, PEAKS_DT, n_rois)
+        if (pk["n_peaks"] < 0).any():
+            raise LfaError(-1, f"ROI {int(np.flatnonzero(pk['n_peaks'] < 0)[0])} was rejected by the device")
+        pr = profiles.cpu().numpy().reshape(n_rois, stride)
+        return [pr[i, :max(0, pk[i]["length"])].copy() for i in range(n_rois)], pk.copy()
 
     def peaks(self, profiles_list, inverse=False, window_size=25, two_peaks=False, rng=15):
         n = len(profiles_list)

@@ -555,6 +555,65 @@ hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const i
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Regions of the other element types np.nanmean takes (lfa_profile_any_batch): int8 / int16 / int32 / uint32 -- np.mean
+// accumulates them in float64, exact while the sums stay below 2^53, so an integer row sum and one division -- and
+// float64: NaNs count as 0 and are left out of the divisor (numpy nanfunctions _replace_nan, sum, _divide_by_count), and
+// the row sum is numpy's pairwise sum over the w * c elements of the (copied, hence contiguous) window row
+// (lfa_algo.h np_pairwise; checked row by row against fixtures made by the reference's own lines).  One wave per ROI, a
+// lane per row: these are single regions handed over by a caller, not the batched hot path.
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+struct NanZeroAt {                     // element i of a row, NaN -> 0
+    const T* p;
+    __device__ double operator()(int i) const { const double x = (double)p[i]; return x != x ? 0.0 : x; }
+};
+
+template <class T>
+__global__ __launch_bounds__(64) void k_profile_any(const T* data, int n, int H, int W, int C, const LfaRoi* rois, int n_rois,
+                                                    double* profiles, int stride, LfaPeaks* peaks) {
+    const int ri = blockIdx.x;
+    const LfaRoi roi = rois[ri];
+    const int len = roi.r1 - roi.r0;
+    const bool bad = roi.image < 0 || roi.image >= n || roi.r0 < 0 || roi.r1 > H || roi.c0 < 0 || roi.c1 > W || len < 0 ||
+                     roi.c1 < roi.c0 || len > stride;
+    if (bad) { if (threadIdx.x == 0) store_bad(&peaks[ri], len); return; }     // k_peaks skips it by the same test
+    const int ne = (roi.c1 - roi.c0) * C;
+    const T* base = data + (int64_t)roi.image * H * W * C;
+    double* prof = profiles + (int64_t)ri * stride;
+    for (int r = threadIdx.x; r < len; r += 64) {
+        const T* row = base + ((int64_t)(roi.r0 + r) * W + roi.c0) * C;
+        if constexpr (sizeof(T) == 8) {                                       // float64
+            int cnt = 0;
+            for (int k = 0; k < ne; ++k) { const double x = (double)row[k]; cnt += (x == x); }
+            const double tot = np_pairwise(NanZeroAt<T>{row}, 0, ne);
+            prof[r] = tot / (double)cnt;                                      // no finite element: 0 / 0 = NaN, as numpy
+        } else {
+            long long sm = 0;
+            for (int k = 0; k < ne; ++k) sm += (long long)row[k];
+            prof[r] = (double)sm / (double)ne;
+        }
+    }
+}
+
+hipError_t launch_profiles_any(const void* data, int elem, int n, int H, int W, int C, const LfaRoi* rois, int n_rois, int inverse,
+                               int rng, double* profiles, int stride, LfaPeaks* peaks, hipStream_t s) {
+    if (n_rois <= 0) return hipSuccess;
+    const dim3 grid(n_rois), block(64);
+    switch (elem) {
+        case LFA_E_I8:  LFA_LAUNCH("k_profile_any", k_profile_any<int8_t>, grid, block, 0, s, (const int8_t*)data, n, H, W, C, rois, n_rois, profiles, stride, peaks); break;
+        case LFA_E_I16: LFA_LAUNCH("k_profile_any", k_profile_any<int16_t>, grid, block, 0, s, (const int16_t*)data, n, H, W, C, rois, n_rois, profiles, stride, peaks); break;
+        case LFA_E_I32: LFA_LAUNCH("k_profile_any", k_profile_any<int32_t>, grid, block, 0, s, (const int32_t*)data, n, H, W, C, rois, n_rois, profiles, stride, peaks); break;
+        case LFA_E_U32: LFA_LAUNCH("k_profile_any", k_profile_any<uint32_t>, grid, block, 0, s, (const uint32_t*)data, n, H, W, C, rois, n_rois, profiles, stride, peaks); break;
+        case LFA_E_F64: LFA_LAUNCH("k_profile_any", k_profile_any<double>, grid, block, 0, s, (const double*)data, n, H, W, C, rois, n_rois, profiles, stride, peaks); break;
+        default: return hipErrorInvalidValue;
+    }
+    Job j{};
+    j.n = n; j.H = H; j.W = W; j.C = C;
+    launch_peaks_k(profiles, nullptr, n_rois, stride, stride, inverse, 25, 1, rng, peaks, j, rois, nullptr, 0, nullptr, 0, s);
+    return hipGetLastError();
+}
+
 hipError_t launch_peaks(const double* profiles, const int32_t* lengths, int n, int stride, int inverse, int window,
                         int two, int rng, LfaPeaks* out, hipStream_t s) {
     if (n <= 0) return hipSuccess;

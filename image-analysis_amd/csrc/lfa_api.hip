@@ -585,6 +585,24 @@ int lfa_profile_lut_batch(LfaHandle h, const void* images, int dtype, int n, int
                         profile_stride, out_peaks, stream);
 }
 
+int lfa_profile_any_batch(LfaHandle h, const void* regions, int elem_type, int n, int H, int W, int C, const LfaRoi* rois,
+                          int n_rois, int inverse, int range, double* out_profiles, int profile_stride, LfaPeaks* out_peaks,
+                          void* stream) {
+    if (!h) return fail(LFA_ERR_ARG, "null handle");
+    if (elem_type == LFA_U8 || elem_type == LFA_U16)
+        return lfa_profile_batch(h, regions, elem_type, n, H, W, C, rois, n_rois, inverse, range, out_profiles, profile_stride, out_peaks, stream);
+    if (elem_type < LFA_E_I8 || elem_type > LFA_E_F64) return fail(LFA_ERR_ARG, "unknown element type %d", elem_type);
+    if (!regions || !rois || !out_profiles || !out_peaks) return fail(LFA_ERR_ARG, "null pointer");
+    if (n < 1 || H < 1 || W < 1 || (C != 1 && C != 3 && C != 4 && C != 2)) return fail(LFA_ERR_ARG, "bad shape n=%d %dx%dx%d", n, H, W, C);
+    if (n_rois < 0 || profile_stride < 1) return fail(LFA_ERR_ARG, "bad n_rois / profile_stride");
+    LFA_ON_DEVICE(h->device);
+    TimerScope ts(h);
+    hipError_t e = lfa::launch_profiles_any(regions, elem_type, n, H, W, C, rois, n_rois, inverse, range, out_profiles, profile_stride,
+                                            out_peaks, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(LFA_ERR_HIP, "lfa_profile_any_batch: %s", hipGetErrorString(e));
+    return LFA_OK;
+}
+
 int lfa_peaks_batch(LfaHandle h, const double* profiles, const int32_t* lengths, int n_profiles, int profile_stride,
                     int inverse, int window_size, int two_peaks, int range, LfaPeaks* out_peaks, void* stream) {
     if (!h) return fail(LFA_ERR_ARG, "null handle");

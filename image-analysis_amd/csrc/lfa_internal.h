@@ -125,6 +125,8 @@ hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const i
                            hipStream_t s, int32_t* roi_idx_or_null = nullptr);   // roi_idx: n + 2 words of scratch -> band kernel allowed
 hipError_t launch_peaks(const double* profiles, const int32_t* lengths, int n, int stride, int inverse, int window,
                         int two, int rng, LfaPeaks* out, hipStream_t s);
+hipError_t launch_profiles_any(const void* data, int elem, int n, int H, int W, int C, const LfaRoi* rois, int n_rois, int inverse,
+                               int rng, double* profiles, int stride, LfaPeaks* peaks, hipStream_t s);
 hipError_t launch_gaussian_w(const Job& j, const double* w, int radius, void* out, int out_f32, hipStream_t s);
 constexpr int kGaussMaxRadius = 8;
 hipError_t launch_debug(const Job& j, int image, int what, void* out, int64_t out_bytes, hipStream_t s);

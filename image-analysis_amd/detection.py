@@ -138,9 +138,19 @@ def _peaks_to_list(pk):
     return out
 
 
+_OTHER_REGION_DTYPES = ("int8", "int16", "int32", "uint32", "float64")       # what lfa_profile_any_batch takes
+
+
 def _analysis(region, selected, rng, inverse, lut=None):
     region = np.asanyarray(region)
-    _check_pixels(region)
+    other = False
+    if region.dtype == np.bool_:
+        region = region.view(np.uint8)                        # np.mean of a bool array is the mean of its 0 / 1 bytes
+    elif region.dtype.name in _OTHER_REGION_DTYPES and lut is None:
+        other = True
+    elif region.dtype not in (np.uint8, np.uint16):
+        raise NotImplementedError(f"region dtype {region.dtype}: the HIP path takes bool, uint8, uint16, int8, int16, int32, uint32 "
+                                  "and float64 regions")
     flat, c = _as_2d_elements(region)
     h, we = flat.shape
     w = we // c
@@ -156,7 +166,10 @@ def _analysis(region, selected, rng, inverse, lut=None):
     roi = np.zeros(1, dtype=_capi.ROI_DT)
     roi["image"], roi["r0"], roi["r1"], roi["c0"], roi["c1"] = 0, r0, r1, c0 * c, c1 * c
     eng = _engine(h, we)
-    profiles, peaks = eng.profiles(flat[None], roi, inverse=inverse, rng=int(rng), luts=lut)
+    if other:
+        profiles, peaks = eng.profiles_any(flat[None], roi, inverse=inverse, rng=int(rng))
+    else:
+        profiles, peaks = eng.profiles(flat[None], roi, inverse=inverse, rng=int(rng), luts=lut)
     return [profiles[0], _peaks_to_list(peaks[0])]
 
 

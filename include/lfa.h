@@ -190,6 +190,20 @@ int lfa_profile_lut_batch(LfaHandle h, const void* images, int dtype, int n, int
                           int inverse, int range, double* out_profiles, int profile_stride, LfaPeaks* out_peaks,
                           void* stream);
 
+/* image_analysis / inverse_image_analysis on regions of the other element types np.nanmean takes (detection.py:205-281 with
+ * `region` an int8 / int16 / int32 / uint32 or float64 array; bool regions are uint8 0 / 1 and go through lfa_profile_batch).
+ * float64: NaN pixels count as 0 and are left out of the row's divisor (np.nanmean), the row sum is numpy's pairwise sum.
+ * regions: device, n arrays of H*W*C elements; everything else as lfa_profile_batch.  Single regions handed over by a
+ * caller, not a batched hot path: one wave per ROI. */
+#define LFA_E_I8  2
+#define LFA_E_I16 3
+#define LFA_E_I32 4
+#define LFA_E_U32 5
+#define LFA_E_F64 6
+int lfa_profile_any_batch(LfaHandle h, const void* regions, int elem_type, int n, int H, int W, int C, const LfaRoi* rois,
+                          int n_rois, int inverse, int range, double* out_profiles, int profile_stride, LfaPeaks* out_peaks,
+                          void* stream);
+
 /* analyze_peaks(profile, inverse, window_size) on caller-supplied float64 profiles (detection.py:283-316).
  * profiles: device, n_profiles * profile_stride float64; lengths: device int32[n_profiles].
  * out: device LfaPeaks[n_profiles] with n_peaks = 1 (start[0], end[0], area[0]); when `two_peaks` != 0 the full

@@ -452,7 +452,50 @@ def write_detect_lines_fixtures():
     print("detect_lines fixtures:", len(names), "cases")
 
 
+def write_dtype_fixtures():
+    """image_analysis / inverse_image_analysis (the reference's own lines, detection.py:205-316) on regions of the other
+    dtypes np.nanmean takes: float64 (with and without NaNs, rows wider than numpy's 128-element pairwise block), int8,
+    int16, int32, uint32 and bool."""
+    warnings.simplefilter("ignore")
+    ns = load_reference_functions()
+    rng = np.random.default_rng(424242)
+    out, k = {}, 0
+    regs = []
+    for (h, w, c) in ((400, 40, 0), (120, 51, 3), (64, 17, 3), (90, 330, 0), (70, 300, 3), (37, 9, 0), (12, 5, 3)):
+        u = synth_strip(rng, h, w, c, np.uint8, 2)
+        f = u.astype(np.float64) / 255.0 + rng.normal(0, 1e-3, size=u.shape)
+        regs.append(("f64", f))
+        g = f.copy()
+        g[rng.random(g.shape) < 0.02] = np.nan
+        regs.append(("f64nan", g))
+        regs.append(("i8", (u.astype(np.int16) - 128).astype(np.int8)))
+        regs.append(("i16", (u.astype(np.int32) * 150 - 20000).astype(np.int16)))
+        regs.append(("i32", (u.astype(np.int64) * 7000000 - 900000000).astype(np.int32)))
+        regs.append(("u32", (u.astype(np.uint64) * 16000000).astype(np.uint32)))
+        regs.append(("bool", u > int(np.median(u))))
+    for rid, (kind, reg) in enumerate(regs):
+        out[f"r{rid}"] = reg
+        for inverse in (False, True):
+            if inverse and reg.ndim != 3:
+                continue
+            fn = ns["inverse_image_analysis"] if inverse else ns["image_analysis"]
+            for selected in (False, True):
+                try:
+                    prof, peaks = fn(reg, selected)
+                except ValueError:
+                    continue
+                n, idx, area = pack_peaks(peaks)
+                out[f"c{k}_rid"] = np.array(rid); out[f"c{k}_selected"] = np.array(selected); out[f"c{k}_inverse"] = np.array(inverse)
+                out[f"c{k}_profile"] = prof; out[f"c{k}_n"] = np.array(n); out[f"c{k}_idx"] = idx; out[f"c{k}_area"] = area
+                k += 1
+    out["n_cases"] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, "ref_profile_dtypes.npz"), **out)
+    print("dtype fixtures:", len(regs), "regions,", k, "cases")
+
+
 if __name__ == "__main__":
+    if "--only-dtypes" in sys.argv:
+        sys.exit(write_dtype_fixtures())
     if "--only-lines" in sys.argv:
         sys.exit(write_detect_lines_fixtures())
     if "--only-samples" in sys.argv:

@@ -477,3 +477,25 @@ def test_gaussian_float32_output(shape, dtype, sigma):
             np.testing.assert_allclose(got[k].astype(np.float64), want, rtol=0, atol=1e-6)
     finally:
         eng.close()
+
+
+def test_regions_of_other_dtypes_equal_the_reference_run():
+    """The drop-in's image_analysis / inverse_image_analysis on float64 (NaNs, rows wider than numpy's 128-element pairwise
+    block), int8, int16, int32, uint32 and bool regions against vectors made by the reference's own lines
+    (tests/golden/ref_profile_dtypes.npz): profiles, peak indices and areas bit for bit (lfa_profile_any_batch)."""
+    import os
+    import image_analysis_amd.detection as detection
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_profile_dtypes.npz"))
+    kinds = set()
+    for k in range(int(G["n_cases"])):
+        reg = G[f"r{int(G[f'c{k}_rid'])}"]
+        kinds.add(reg.dtype.name)
+        fn = detection.inverse_image_analysis if G[f"c{k}_inverse"] else detection.image_analysis
+        prof, peaks = fn(reg, bool(G[f"c{k}_selected"]))
+        assert prof.dtype == np.float64 and prof.tobytes() == G[f"c{k}_profile"].tobytes(), (k, reg.dtype)
+        assert len(peaks) == int(G[f"c{k}_n"])
+        for i, (s, e, a) in enumerate(peaks):
+            assert [s, e] == G[f"c{k}_idx"][i].tolist() and np.float64(a).tobytes() == G[f"c{k}_area"][i].tobytes(), (k, i)
+    assert len(kinds) == 6
+    with pytest.raises(NotImplementedError):
+        detection.image_analysis(np.zeros((40, 20), np.float32), True)

@@ -152,3 +152,22 @@ def test_point_operations_match_the_reference_docstrings():
     assert O.rescale_intensity(img, (100, 100)).tolist() == [100, 100, 100]
     with pytest.raises(TypeError):
         O.rescale_intensity(img, (None, 100))
+
+
+def test_profiles_of_other_region_dtypes_equal_the_reference_run():
+    """image_analysis / inverse_image_analysis on float64 (with NaNs, rows beyond numpy's 128-element pairwise block), int8,
+    int16, int32, uint32 and bool regions: vectors made by the reference's own lines (make_golden.py --only-dtypes)."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_profile_dtypes.npz"))
+    from oracle import lfa_oracle as O
+    kinds = set()
+    for k in range(int(G["n_cases"])):
+        reg = G[f"r{int(G[f'c{k}_rid'])}"]
+        kinds.add(reg.dtype.name)
+        fn = O.inverse_image_analysis if G[f"c{k}_inverse"] else O.image_analysis
+        prof, peaks = fn(reg, bool(G[f"c{k}_selected"]))
+        assert prof.dtype == np.float64 and prof.tobytes() == G[f"c{k}_profile"].tobytes()
+        assert len(peaks) == int(G[f"c{k}_n"])
+        for i, (s, e, a) in enumerate(peaks):
+            assert [s, e] == G[f"c{k}_idx"][i].tolist() and np.float64(a).tobytes() == G[f"c{k}_area"][i].tobytes()
+    assert kinds == {"float64", "int8", "int16", "int32", "uint32", "bool"}
