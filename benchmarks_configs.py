@@ -135,7 +135,7 @@ def bench_u16(B=1024, CH=256, pool=8, real=False, steps=10):
     dt = timed(pl.step, steps)
     kt = pl.kernel_times()
     ns, inf = pl.results()
-    out = {"config": "the reference's 12-bit frame excel2 (2048x2048 uint16), rolled per pool slot" if real else "configs[2]: 2048x2048 uint16 frames, synthetic, 40 strips each",
+    out = {"config": f"{B} resident copies of the reference's 12-bit frame excel2 (2048x2048 uint16), rolled per pool slot" if real else f"configs[2]: {B} resident 2048x2048 uint16 frames (pool of {pool} synthetic frames, 40 strips each, replicated)",
            "frames": B, "chunk": CH, "streams": pl.NS, "pool": pool, "steps": steps, "ms_per_step": round(dt * 1e3, 3),
            "frames_per_s": round(B / dt, 1), "strips_per_s": round(ns / dt, 1), "labels_mean": float(inf["n_labels"].mean()),
            "runs_mean": float(inf["n_runs"].mean()), "algorithmic_bytes_per_step": B * pl.ib,
@@ -194,31 +194,45 @@ def bench_photo(B=1024, CH=256, pool=8, steps=10):
     return out
 
 
-def bench_rois(B=64, per=256, steps=10):
-    """configs[4]: dense select-region workload, 256 ROIs per image (h ~ U{64..512}, w ~ U{16..64}), profile + peaks."""
+def bench_rois(B=64, per=256, steps=10, CH=256):
+    """configs[4]: dense select-region workload, 256 ROIs per image (h ~ U{64..512}, w ~ U{16..64}), profile + peaks.
+    B = 4096 is BASELINE.json's size (4096 images x 256 ROIs, all resident: 38.7 GB of images, 1 048 576 ROIs); the images
+    go through lfa_profile_batch in calls of CH images."""
     H, W = 1536, 2048
+    CH = min(CH, B)
     pool_np = np.stack([synth.synth_rgb(H, W, 8, 1234 + i) for i in range(8)])
     p = torch.from_numpy(pool_np.reshape(8, -1)).to(DEV())
     batch = p[torch.arange(B, device=DEV()) % 8].contiguous()
+    del p
     rois = synth.synth_rois(B, H, W, per).astype(capi.ROI_DT)
-    rt = capi.to_device(rois, DEV())
     n = len(rois)
     stride = 512
-    eng = capi.Engine(device=DEV().index, max_h=H, max_w=W, max_c=3, max_batch=B)
+    ib = H * W * 3
+    chunks = []                                           # (first image, images, device ROI array rebased to the chunk, first ROI, ROIs)
+    for b0 in range(0, B, CH):
+        sel = np.flatnonzero((rois["image"] >= b0) & (rois["image"] < b0 + CH))
+        assert len(sel) and np.array_equal(sel, np.arange(sel[0], sel[0] + len(sel)))
+        r = rois[sel].copy()
+        r["image"] -= b0
+        chunks.append((b0, min(CH, B - b0), capi.to_device(r, DEV()), int(sel[0]), len(sel)))
+    eng = capi.Engine(device=DEV().index, max_h=H, max_w=W, max_c=3, max_batch=CH)
     prof = torch.empty(n * stride, dtype=torch.float64, device=DEV()); peaks = capi.dev_bytes(n * 40, DEV())
     st = capi.current_stream_ptr(DEV())
 
     def step():
-        capi._check(capi.lib.lfa_profile_batch(eng._h, batch.data_ptr(), capi.LFA_U8, B, H, W, 3, rt.data_ptr(), n, 0, 15,
-                                               prof.data_ptr(), stride, peaks.data_ptr(), st))
+        for b0, nb, rt, r0, nr in chunks:
+            capi._check(capi.lib.lfa_profile_batch(eng._h, batch.data_ptr() + b0 * ib, capi.LFA_U8, nb, H, W, 3, rt.data_ptr(), nr, 0, 15,
+                                                   prof.data_ptr() + r0 * stride * 8, stride, peaks.data_ptr() + r0 * 40, st))
     dt = timed(step, steps)
     eng.timing("*"); step(); torch.cuda.synchronize(); kt = eng.timing_read(); eng.timing(None)
     byts = int(((rois["r1"] - rois["r0"]).astype(np.int64) * (rois["c1"] - rois["c0"]) * 3).sum())
-    out = {"config": "configs[4]: dense select-region, 256 ROIs per image on 1536x2048 RGB images (profile + peaks)", "images": B,
-           "rois": n, "steps": steps, "ms_per_step": round(dt * 1e3, 3), "rois_per_s": round(n / dt, 1),
+    pk = capi.from_device(peaks, capi.PEAKS_DT, n)
+    assert (pk["n_peaks"] >= 1).all()
+    out = {"config": f"configs[4]: dense select-region, 256 ROIs per image on {B} resident 1536x2048 RGB images (profile + peaks), {CH} images per call",
+           "images": B, "rois": n, "steps": steps, "ms_per_step": round(dt * 1e3, 3), "rois_per_s": round(n / dt, 1),
            "algorithmic_bytes_per_step": byts, "GBps_algorithmic": round(byts / dt / 1e9, 1),
            "e2e_frac_hbm": round(byts / dt / (HBM_PEAK_GBS * 1e9), 4),
-           "dominant": dominant(kt, lambda k: byts if k in ("k_profile", "k_profile_band") else None), "kernel_ms": _kernel_table(kt)}
+           "dominant": dominant(kt, lambda k: byts // len(chunks) if k in ("k_profile", "k_profile_band") else None), "kernel_ms": _kernel_table(kt)}
     eng.close()
     return out
 
@@ -334,11 +348,11 @@ def named(name, steps=10):
     if name == "big":
         return {"configs[3]": big_with_gather(steps)}
     if name == "u16":
-        return {"configs[2]": bench_u16(steps=steps)}
+        return {"configs[2]": bench_u16(B=10240, steps=steps)}          # BASELINE.json: the stack replicated to 10k frames, all resident
     if name == "u16real":
-        return {"configs[2]_excel2_frame": bench_u16(real=True, steps=steps)}
+        return {"configs[2]_excel2_frame": bench_u16(B=10240, real=True, steps=steps)}
     if name == "rois":
-        return {"configs[4]": bench_rois(steps=steps)}
+        return {"configs[4]": bench_rois(B=4096, steps=steps)}          # BASELINE.json: 256 ROIs per image x 4096 images
     if name == "gauss":
         g = bench_gauss(steps=steps)
         return {"gaussian_rgb_u8_f64": g[0], "gaussian_u16_f64": g[1], "gaussian_rgb_u8_f32": g[2]}
