@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=3, help="lanes (one LfaHandle + one HIP stream each) the chunks take in turn")
     ap.add_argument("--stagger", type=int, default=2, help="0: lanes run free; 1: a chunk's kernels start when the previous chunk's histogram pass is done (lfa_stream_wait_passes); 2: only its image passes wait (lfa_chain_passes)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--free-running", action="store_true", help="after the timed region, time the same steps again with no ordering between the lanes (reported as `free_running`); off by default so that a profile of the default command holds one schedule only")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary configurations (the `configs` object)")
     ap.add_argument("--config-steps", type=int, default=10, help="timed steps of each secondary configuration")
     return ap.parse_args()
@@ -267,7 +268,7 @@ def main():
 
     # ---- the same steps with the lanes running free (no ordering between their passes): reported beside the timed region ----
     free = None
-    if NS > 1 and args.stagger == 2:
+    if NS > 1 and args.stagger == 2 and args.free_running:
         for e in engs:
             capi._check(capi.lib.lfa_chain_passes(e._h, None))
         for _ in range(max(1, args.warmup)):

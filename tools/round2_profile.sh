@@ -21,8 +21,10 @@ run_stats cfg2 $R/benchmarks_configs.py u16 && echo stats cfg2 ok &&
 run_stats cfg3 $R/benchmarks_configs.py big && echo stats cfg3 ok &&
 run_stats cfg4 $R/benchmarks_configs.py rois && echo stats cfg4 ok &&
 run_stats gauss $R/benchmarks_configs.py gauss && echo stats gauss ok &&
+run_stats lines $R/benchmarks_configs.py lines && echo stats lines ok &&
 run_pmc bench FETCH_SIZE $HEAD --batch 512 --steps 1 --warmup 1 && run_pmc bench WRITE_SIZE $HEAD --batch 512 --steps 1 --warmup 1 && echo pmc bench ok &&
 run_pmc cfg2 FETCH_SIZE $R/benchmarks_configs.py u16 && run_pmc cfg2 WRITE_SIZE $R/benchmarks_configs.py u16 && echo pmc cfg2 ok &&
 run_pmc cfg4 FETCH_SIZE $R/benchmarks_configs.py rois && run_pmc cfg4 WRITE_SIZE $R/benchmarks_configs.py rois && echo pmc cfg4 ok &&
-run_pmc gauss FETCH_SIZE $R/benchmarks_configs.py gauss && run_pmc gauss WRITE_SIZE $R/benchmarks_configs.py gauss && echo pmc gauss ok
+run_pmc gauss FETCH_SIZE $R/benchmarks_configs.py gauss && run_pmc gauss WRITE_SIZE $R/benchmarks_configs.py gauss && echo pmc gauss ok &&
+run_pmc lines FETCH_SIZE $R/benchmarks_configs.py lines && run_pmc lines WRITE_SIZE $R/benchmarks_configs.py lines && echo pmc lines ok
 find $O -name "*.csv" | head -40

@@ -14,9 +14,9 @@ import sys
 
 SRC = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02"
 DST = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-CMD = {"bench": "bench.py --cpu-sample 0 --no-configs (stats) / ... --no-kernel-timing --batch 512 --steps 1 --warmup 1 (pmc)",
+CMD = {"bench": "bench.py --cpu-sample 0 --no-configs (stats; the default schedule only, its JSON line in r02_bench_under_rocprof.json) / ... --no-kernel-timing --batch 512 --steps 1 --warmup 1 (pmc)",
        "cfg2": "benchmarks_configs.py u16", "cfg3": "benchmarks_configs.py big", "cfg4": "benchmarks_configs.py rois",
-       "gauss": "benchmarks_configs.py gauss"}
+       "gauss": "benchmarks_configs.py gauss", "lines": "benchmarks_configs.py lines"}
 
 
 def short(name):
