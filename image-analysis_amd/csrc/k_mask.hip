@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
                 else if (integer_path) {
                     bit = (2125u * base[3 * px] + 7154u * base[3 * px + 1] + 721u * base[3 * px + 2]) >= G_thr;
                 } else {
-                    const double g = gray_u8<V>(base[3 * px], base[3 * px + 1], base[3 * px + 2]);
+                    const double g = gray_at<V>(base, px, j.dtype == LFA_U16);
                     bit = g > g_thr;
                     amb += near_rel(g, g_next) ? 1u : 0u;
                 }

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void k_box_sums(Job j) {
                 const int64_t rowpx = (int64_t)r * j.W;
                 for (int c = minc + lane; c < maxc; c += 64) {
                     const int64_t px = rowpx + c;
-                    if (j.C == 3) { s0 += base[3 * px]; s1 += base[3 * px + 1]; s2 += base[3 * px + 2]; }
+                    if (j.C == 3 && esz == 2) { const uint16_t* b16 = (const uint16_t*)base; s0 += b16[3 * px]; s1 += b16[3 * px + 1]; s2 += b16[3 * px + 2]; }
+                    else if (j.C == 3) { s0 += base[3 * px]; s1 += base[3 * px + 1]; s2 += base[3 * px + 2]; }
                     else if (esz == 1) s0 += base[px];
                     else s0 += ((const uint16_t*)base)[px];
                 }

@@ -279,6 +279,7 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
     j.gray_variant = h->gray_variant;
     j.debug_flags = h->debug_flags;
     j.aligned16 = (((uintptr_t)images & 15) == 0 && (j.img_bytes & 15) == 0) ? 1 : 0;
+    if (C == 3 && dtype == LFA_U16) j.aligned16 = 0;         // uint16 colour: the scalar float64 paths of every kernel (rare input, kept simple)
     j.HB = (H + 63) / 64;
     j.run_cap = run_capacity(H, W, L);
     j.max_strips = max_strips;
@@ -310,7 +311,7 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
         } else if (h->debug_flags & 4) { j.u16_pred = 1; j.u16_ps = ps; j.u16_pa = 0; }
         j.u16_plane = (j.u16_pred && w.bins.bytes >= (size_t)n * (((size_t)H * W + 1) / 2) && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->u16_plane_on || (h->debug_flags & 4))) ? 1 : 0;
     }
-    const bool rgb_plane = C == 3 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4));
+    const bool rgb_plane = C == 3 && dtype == LFA_U8 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4));
     j.bins = (j.u16_plane || rgb_plane) ? (uint8_t*)w.bins.p : nullptr;
     j.maskT = (uint64_t*)w.maskT.p;
     j.col_cnt = (uint32_t*)w.col_cnt.p;
@@ -363,7 +364,6 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
                 LfaRoi* out_rois, hipStream_t s, lfa::Job* job_out, bool static_ws = false, LfaRoi** ws_rois = nullptr) {
     int rc = check_images(h, images, dtype, n, H, W, C);
     if (rc) return rc;
-    if (C == 3 && dtype != LFA_U8) return fail(LFA_ERR_UNSUPPORTED, "colour images must be uint8 (uint16 colour is not implemented)");
     if (H > 65535 || W > 65535) return fail(LFA_ERR_ARG, "image sides above 65535 are not supported");
     if ((long long)H * W > (1ll << 30)) return fail(LFA_ERR_UNSUPPORTED, "images above 2^30 pixels are not supported");
     if (L < 1) return fail(LFA_ERR_ARG, "line_length must be >= 1");

@@ -109,6 +109,25 @@ __device__ inline double gray_u8(uint32_t p0, uint32_t p1, uint32_t p2) {
     return fma(x1, c1, x0 * c0) + x2 * c2;
 }
 
+// the same for uint16 colour pixels (x_k = fl(pixel_k * fl(1/65535))) and the pixel of either type at index px of an image
+template <int V>
+__device__ inline double gray_u16(uint32_t p0, uint32_t p1, uint32_t p2) {
+    const double inv = 1.0 / 65535.0;
+    const double c0 = 0.2125, c1 = 0.7154, c2 = 0.0721;
+    const double x0 = (double)p0 * inv, x1 = (double)p1 * inv, x2 = (double)p2 * inv;
+    if (V == LFA_GRAY_FMA_102) return fma(x2, c2, fma(x0, c0, x1 * c1));
+    if (V == LFA_GRAY_SEQ) return (x0 * c0 + x1 * c1) + x2 * c2;
+    if (V == LFA_GRAY_FMA_012) return fma(x2, c2, fma(x1, c1, x0 * c0));
+    if (V == LFA_GRAY_FMA_210) return fma(x0, c0, fma(x1, c1, x2 * c2));
+    if (V == LFA_GRAY_PAIR) return x0 * c0 + (x1 * c1 + x2 * c2);
+    return fma(x1, c1, x0 * c0) + x2 * c2;
+}
+template <int V>
+__device__ inline double gray_at(const uint8_t* base, int64_t px, bool u16) {
+    if (u16) { const uint16_t* b = (const uint16_t*)base; return gray_u16<V>(b[3 * px], b[3 * px + 1], b[3 * px + 2]); }
+    return gray_u8<V>(base[3 * px], base[3 * px + 1], base[3 * px + 2]);
+}
+
 // ---- integer gray G = 2125*b0 + 7154*b1 + 721*b2 of pixel k (0..15) of a 48-byte group -----------------------------------
 // (k_threshold.hip explains why compares on G are exact).  A pixel that straddles two dwords is brought together with
 // v_alignbyte; then two v_dot4_u32_u8: weights split as hi*256 + lo, placed where the pixel's bytes sit, the fourth byte weighs 0.

@@ -312,6 +312,13 @@ def skimage_detect_cases():
     cases.append(("edges_rgb", np.ascontiguousarray(np.stack([e, np.clip(e.astype(int) + 2, 0, 255).astype(np.uint8), e], axis=2)), 100, 5, 10))
     cases.append(("edges_u16", (e.astype(np.uint16) * 13), 100, 5, 10))
     cases.append(("edges_u8_L3", e.copy(), 30, 5, 3))
+    # uint16 colour images (16-bit RGB TIFFs): a foreground corner and borders, synthetic strips with 16-bit noise, a constant image
+    e16 = np.stack([e.astype(np.uint16) * 257, np.clip(e.astype(int) + 2, 0, 255).astype(np.uint16) * 257 + 100, e.astype(np.uint16) * 250], axis=2)
+    cases.append(("edges_rgb16", np.ascontiguousarray(e16), 100, 5, 10))
+    c8 = synth_rgb(192, 256, 4, 31)
+    c16 = (c8.astype(np.uint16) << 8) | rng.integers(0, 256, size=c8.shape).astype(np.uint16)
+    cases.append(("synth_rgb16_192x256", np.ascontiguousarray(c16), *gui(c16[:, :, 0]), 10))
+    cases.append(("constant_rgb16", np.full((40, 44, 3), 3000, np.uint16), 20, 3, 10))
     return cases
 
 

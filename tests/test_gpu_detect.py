@@ -609,3 +609,35 @@ def test_random_small_images_against_oracle(capi, eng, seed):
             check_detect(capi, eng, arr, mm_r, mm_c, L)
         finally:
             eng.set_debug_flags(0)
+
+
+def test_uint16_colour_images_detect_profile_and_peaks():
+    """16-bit RGB images (what tifffile hands the reference for an RGB16 TIFF): the scalar float64 paths of every kernel.
+    detect against the oracle (threshold, boxes), then the whole batch call against detect + image_analysis of the oracle;
+    the detect stage is also held to the vendored-skimage fixtures in test_gpu_skimage.py (cases *_rgb16)."""
+    import image_analysis_amd.detection as detection
+    from image_analysis_amd.synth import synth_rgb
+    from oracle import lfa_oracle as O
+    rng = np.random.default_rng(3)
+    ims = []
+    for seed in (41, 42):
+        c8 = synth_rgb(192, 256, 4, seed)
+        ims.append(((c8.astype(np.uint16) << 8) | rng.integers(0, 256, size=c8.shape).astype(np.uint16)))
+    ims = np.stack(ims)
+    mm_c = int(256 / 40)
+    detection.min_maxr, detection.min_maxc = mm_c * 20, mm_c
+    try:
+        got = detection.analyze_batch(ims)
+        for im, res in zip(ims, got):
+            want_crops = O.detect_lateral_flow_tests(im, mm_c * 20, mm_c)
+            assert len(res) == len(want_crops) > 0
+            for (crop, prof, peaks), wc in zip(res, want_crops):
+                assert crop.shape == wc.shape and np.array_equal(crop, wc)
+                wp, wpk = O.image_analysis(wc, False)
+                assert prof.tobytes() == wp.tobytes()
+                assert [(s, e) for s, e, _ in peaks] == [(s, e) for s, e, _ in wpk]
+                assert all(np.float64(a).tobytes() == np.float64(b).tobytes() for (_, _, a), (_, _, b) in zip(peaks, wpk))
+            single = detection.detect_lateral_flow_tests(im)
+            assert [c.shape for c in single] == [c.shape for c in want_crops]
+    finally:
+        detection.min_maxr, detection.min_maxc = 0, 0
