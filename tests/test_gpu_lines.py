@@ -95,6 +95,19 @@ def test_hip_equals_oracle_on_larger_and_odd_frames(capi, eng, shape, dtype, see
         assert d["strips"] == [[100, 107, 0, 512], [293, 300, 0, 512]]
 
 
+@pytest.mark.parametrize("key", ["image2", "image4", "image7", "wick_crop", "image5_crop", "austin_u16_crop", "strip_channel0", "excel2_frame"])
+def test_hip_equals_oracle_on_the_reference_sample_images(capi, eng, key):
+    """the reference's own sample inputs (decoded in the build container, tests/golden/real_samples.npz), its 12-bit frame, and
+    one channel of its strip crop -- the kind of image detect_lines was written for"""
+    if key == "excel2_frame":
+        from PIL import Image
+        im = np.array(Image.open(os.path.join(GOLDEN, "excel2_frame.png")))[:1024, :1536]
+    else:
+        rs = np.load(os.path.join(GOLDEN, "real_samples.npz"))
+        im = np.ascontiguousarray(rs["test_strip_buggy_bgr"][:, :, 0]) if key == "strip_channel0" else rs[key]
+    _against_oracle(capi, eng, im)
+
+
 def test_batch_of_different_images_and_box_overflow(capi, eng):
     from oracle import lines_oracle as L
     ims = np.stack([G["tiny_seed2__image"], G["tiny_seed7__image"], G["tiny_seed23__image"]])
