@@ -285,7 +285,7 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
     j.max_strips = max_strips;
     j.info = (LfaImageInfo*)w.info.p;
     j.hist = (uint32_t*)w.hist.p;
-    j.hist_stride = (dtype == LFA_U16) ? lfa::kHistBinsU16 : 256;
+    j.hist_stride = (dtype == LFA_U16 && C == 1) ? lfa::kHistBinsU16 : 256;      // (uint16 colour: the 256 float bins of the colour path)
     j.otsu_w = (float*)w.otsu_w.p;
     j.otsu_s = (double*)w.otsu_s.p;
     j.edges_g = (double*)w.edges.p;

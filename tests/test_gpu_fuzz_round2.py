@@ -1,0 +1,110 @@
+"""Seeded fuzz over the paths added in round 2, HIP against the oracle, through the drop-in module and the C ABI:
+detect_lines on small frames of random shape and content, detect on uint16 colour images, image_analysis on regions of the
+other dtypes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(rng, H, W, dtype):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        a = rng.integers(0, 256, size=(H, W)).astype(np.float64)
+    elif kind == 1:                                                   # blocks of equal value: components larger than a pixel
+        a = np.kron(rng.integers(0, 256, size=((H + 3) // 4, (W + 3) // 4)), np.ones((4, 4)))[:H, :W].astype(np.float64)
+    elif kind == 2:                                                   # gradient with a few saturated rows
+        a = np.add.outer(np.linspace(20, 200, H), np.linspace(0, 40, W)) + rng.normal(0, 2, (H, W))
+        for r in rng.integers(0, H, size=max(1, H // 16)):
+            a[r, :] = 255
+    else:
+        a = rng.normal(100, 30, size=(H, W))
+    a = np.clip(a, 0, 255)
+    return a.astype(np.uint8) if dtype == np.uint8 else (a * 257).astype(np.uint16)
+
+
+def test_detect_lines_fuzz():
+    import image_analysis_amd.detection as detection
+    from oracle import lines_oracle as L
+    rng = np.random.default_rng(20261111)
+    nonempty = 0
+    for it in range(40):
+        H, W = int(rng.integers(2, 97)), int(rng.integers(2, 97))
+        im = _frame(rng, H, W, np.uint8 if it % 2 else np.uint16)
+        try:
+            want = L.detect_lines(im)
+        except ValueError as e:
+            with pytest.raises(ValueError):
+                detection.detect_lines(im)
+            continue
+        got = detection.detect_lines(im)
+        assert got == want, (it, H, W, im.dtype)
+        nonempty += bool(want)
+    assert nonempty >= 5
+
+
+def test_uint16_colour_detect_fuzz():
+    import image_analysis_amd.detection as detection
+    from oracle import lfa_oracle as O
+    rng = np.random.default_rng(77)
+    found = 0
+    try:
+        for it in range(12):
+            H, W = int(rng.integers(60, 200)), int(rng.integers(40, 180))
+            im = rng.integers(500, 9000, size=(H, W, 3)).astype(np.uint16)
+            for _ in range(int(rng.integers(1, 4))):
+                c0 = int(rng.integers(0, W - 8)); w = int(rng.integers(3, 9)); r0 = int(rng.integers(0, H // 2)); h = int(rng.integers(12, H // 2))
+                im[r0:r0 + h, c0:c0 + w] = rng.integers(40000, 65536, size=(h, min(w, W - c0), 3))
+            detection.min_maxr, detection.min_maxc = int(rng.integers(0, 40)), int(rng.integers(0, 8))
+            L = int(rng.choice([3, 10]))
+            want = O.detect_lateral_flow_tests(im, detection.min_maxr, detection.min_maxc, L)
+            got = detection.detect_lateral_flow_tests(im, L)
+            assert len(got) == len(want), it
+            for a, b in zip(got, want):
+                assert a.shape == b.shape and np.array_equal(a, b)
+            found += len(want)
+    finally:
+        detection.min_maxr, detection.min_maxc = 0, 0
+    assert found >= 10
+
+
+def test_region_dtype_fuzz():
+    import image_analysis_amd.detection as detection
+    from oracle import lfa_oracle as O
+    rng = np.random.default_rng(5150)
+    for it in range(40):
+        h, w = int(rng.integers(8, 200)), int(rng.integers(4, 150))
+        c = int(rng.choice([0, 3]))
+        shape = (h, w, c) if c else (h, w)
+        rows = np.arange(h).reshape((h, 1, 1) if c else (h, 1))
+        base = 120 + 60 * np.exp(-0.5 * ((rows - h * rng.uniform(0.3, 0.55)) / max(2.0, h * 0.04)) ** 2) + rng.normal(0, 3, size=shape)
+        kind = ["float64", "int8", "int16", "int32", "uint32", "bool", "float64nan"][it % 7]
+        if kind == "float64":
+            reg = base / 255.0
+        elif kind == "float64nan":
+            reg = base / 255.0
+            reg[rng.random(shape) < 0.05] = np.nan
+        elif kind == "bool":
+            reg = base > 125
+        elif kind == "int8":
+            reg = (base - 128).clip(-128, 127).astype(np.int8)
+        elif kind == "int16":
+            reg = (base * 100 - 20000).astype(np.int16)
+        elif kind == "int32":
+            reg = (base * 5e6 - 9e8).astype(np.int32)
+        else:
+            reg = (base * 1.5e7).astype(np.uint32)
+        selected = bool(rng.integers(0, 2))
+        inverse = bool(c and rng.integers(0, 2))
+        fn_o = O.inverse_image_analysis if inverse else O.image_analysis
+        fn_g = detection.inverse_image_analysis if inverse else detection.image_analysis
+        try:
+            wp, wk = fn_o(reg, selected)
+        except ValueError:
+            with pytest.raises(ValueError):
+                fn_g(reg, selected)
+            continue
+        gp, gk = fn_g(reg, selected)
+        assert gp.tobytes() == wp.tobytes(), (it, kind, shape)
+        assert [(s, e) for s, e, _ in gk] == [(s, e) for s, e, _ in wk]
+        assert all(np.float64(a).tobytes() == np.float64(b).tobytes() for (_, _, a), (_, _, b) in zip(gk, wk))
