@@ -371,7 +371,13 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (!out_strips || !out_counts) return fail(LFA_ERR_ARG, "null output pointer");
     if (max_strips < 1 || max_strips > 1024) return fail(LFA_ERR_ARG, "max_strips must be in [1,1024]");
     LFA_ON_DEVICE(h->device);
-    if (h->plane_pending && hipEventQuery(h->plane_event) == hipSuccess) {                // an earlier call's counters have arrived
+    // The counters of the handle's previous call select this call's paths, so the set-up WAITS for them (a 48-byte copy that
+    // trails that call's kernels): which path a call takes is then a function of the calls made on the handle, not of how far
+    // the device had got when the next call was set up.  The host therefore runs at most one call ahead per handle; callers
+    // that pipeline use several handles (bench.py, frames.analyze_stream), and the device still has the other handles' calls
+    // queued while this one waits.  LFA_POLL_COUNTERS=1 restores the non-blocking look (hipEventQuery) for comparison.
+    static const bool poll = [] { const char* e = getenv("LFA_POLL_COUNTERS"); return e && *e == '1'; }();
+    if (h->plane_pending && (poll ? hipEventQuery(h->plane_event) == hipSuccess : hipEventSynchronize(h->plane_event) == hipSuccess)) {
         h->plane_pending = false;
         if (h->plane_host[1]) h->plane_on = 2u * h->plane_host[0] >= h->plane_host[1];
         if (h->plane_host[3]) { h->u16_max = (int)h->plane_host[2]; h->u16_one_pass = h->plane_host[2] < (uint32_t)lfa::kLdsBinsU16; }

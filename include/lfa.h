@@ -13,7 +13,10 @@
  *     unless a parameter is documented as host memory; images are C-contiguous, batch-major:
  *     image i starts at byte i * H*W*C*sizeof(pixel);
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls enqueue work and
- *     return without waiting unless documented otherwise; one handle per device and per host thread; a handle's
+ *     return without waiting unless documented otherwise -- one documented wait: a detect / analyze call first waits for
+ *     the 48-byte counter block of the handle's PREVIOUS detect / analyze call (it selects between code paths with
+ *     identical results), i.e. the host runs at most one such call ahead per handle; pipeline over several handles;
+ *     one handle per device and per host thread; a handle's
  *     detect / analyze calls share its workspace, so they run in the order they were made even when they name
  *     different streams (a call on another stream than the handle's previous call first waits for that call's event);
  *     a call makes the handle's device current while it runs and leaves the caller's current device as it found it;
