@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LFA_LIB_PATH") or os.path.join(_HERE, "liblfa_hip.so")     # LFA_LIB_PATH: an experimental build (tools/)
 
-LFA_U8, LFA_U16 = 0, 1
+LFA_U8, LFA_U16, LFA_F64 = 0, 1, 6
 ELEM_CODES = {"uint8": 0, "uint16": 1, "int8": 2, "int16": 3, "int32": 4, "uint32": 5, "float64": 6}   # lfa.h LFA_E_*
 DBG_MASK, DBG_OPENED, DBG_LABELS, DBG_TABLE, DBG_HIST, DBG_PLANE, DBG_ONEPASS = 0, 1, 2, 3, 4, 5, 6
 GRAY_NVARIANTS = 6
@@ -229,6 +229,8 @@ def np_dtype_code(dt):
         return LFA_U8
     if dt == np.uint16:
         return LFA_U16
+    if dt == np.float64:
+        return LFA_F64                 # lfa_detect_batch only (lfa.h); every other entry point refuses it
     raise TypeError(f"pixel dtype {dt} is not supported by the HIP path (uint8 and uint16 only)")
 
 
@@ -346,7 +348,7 @@ class Engine:
                     ms = min(1024, ms * 4)
                     continue
                 break
-            if (inf["status"] != 0).any():
+            if (inf["status"] & ~4).any():         # (bit 2: float image with a foreground corner -- the caller's to report, lfa.h)
                 raise LfaError(-3, f"detect overflow (status {inf['status'].tolist()}): more than 1024 strips per image")
             cn = from_device(counts, np.int32, b1 - b0)
             st = from_device(strips, STRIP_DT, (b1 - b0) * ms).reshape(b1 - b0, ms)

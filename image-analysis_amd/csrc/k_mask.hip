@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
                 else if (integer_path) {
                     bit = (2125u * base[3 * px] + 7154u * base[3 * px + 1] + 721u * base[3 * px + 2]) >= G_thr;
                 } else {
-                    const double g = gray_at<V>(base, px, j.dtype == LFA_U16);
+                    const double g = gray_at<V>(base, px, j.dtype, j.C);
                     bit = g > g_thr;
                     amb += near_rel(g, g_next) ? 1u : 0u;
                 }
@@ -254,7 +254,7 @@ static void launch_mode(const Job& j, hipStream_t s) {
 }
 
 hipError_t launch_mask(const Job& j, hipStream_t s) {
-    if (j.C == 3) {
+    if (j.C == 3 || j.dtype == LFA_F64) {                    // gray is a float64: colour images, float64 images
         switch (j.gray_variant) {
             case 0: launch_mode<2, 0>(j, s); break;
             case 1: launch_mode<2, 1>(j, s); break;

@@ -29,6 +29,10 @@ __global__ __launch_bounds__(256) void k_box_sums(Job j) {
     // is `mean > 0`, which always holds: the box contains the component, and every pixel of a component is above a
     // non-negative threshold, hence non-zero.  So the box pass runs only for images whose corner pixel is foreground.
     if (j.info[img].label00 == 0) return;
+    if (j.dtype == LFA_F64) {                                     // float box means (numpy's summation order): not implemented
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&j.info[img].status, 4);
+        return;
+    }
     const int nc = j.info[img].n_candidates;
     const uint8_t* base = j.images + (int64_t)img * j.img_bytes;
     __shared__ unsigned long long part[4][3];

@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void k_edges_rgb(Job j) {
         eg[i] = (i == 0) ? 0u : g_threshold(ti, &crit);       // edge 0 (= gmin) is below every pixel
         anycrit |= (i >= 1 && i <= 255 && crit);
     }
-    // (uint16 colour pixels: the integer form is built for 8-bit channels, they always take the float64 path)
-    const int any = __syncthreads_or((anycrit || (j.debug_flags & 1) || j.dtype == LFA_U16) ? 1 : 0);
+    // (uint16 colour and float64 pixels: the integer form is built for 8-bit channels, they always take the float64 path)
+    const int any = __syncthreads_or((anycrit || (j.debug_flags & 1) || j.dtype != LFA_U8) ? 1 : 0);
     if (threadIdx.x == 0) eg[kEdgesI_Crit] = (uint32_t)any;
 }
 
@@ -269,9 +269,9 @@ __global__ __launch_bounds__(256) void k_minmax_rgb(Job j) {
         }
         done = ng << 4;
     }
-    const bool u16 = j.dtype == LFA_U16;                      // uint16 colour images: this scalar loop only (Job::aligned16 is 0 for them)
+    // uint16 colour and float64 images: this scalar loop only (Job::aligned16 is 0 for them)
     for (int64_t p = done + tid; p < npix; p += nth) {
-        const double gr = gray_at<V>(base, p, u16);
+        const double gr = gray_at<V>(base, p, j.dtype, j.C);
         lo = fmin(lo, gr); hi = fmax(hi, gr);
     }
     lo = wave_min_f64(lo); hi = wave_max_f64(hi);
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
             }
             done = ng << 4;
         }
-        for (int64_t p = done + tid; p < npix; p += nth) add(gray_at<V>(base, p, j.dtype == LFA_U16));
+        for (int64_t p = done + tid; p < npix; p += nth) add(gray_at<V>(base, p, j.dtype, j.C));
     }
     __syncthreads();
     uint32_t tot = 0;
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
     bool crit = false;
     const uint32_t G_thr = g_threshold(T, &crit);
     eg[kEdgesI_MaskThr] = G_thr;
-    eg[kEdgesI_MaskCrit] = (crit || (j.debug_flags & 1) || j.dtype == LFA_U16) ? 1u : 0u;
+    eg[kEdgesI_MaskCrit] = (crit || (j.debug_flags & 1) || j.dtype != LFA_U8) ? 1u : 0u;
     // k_mask may decide from the class plane alone (class > class of best: set, <: clear, ==: exact compare) iff the
     // histogram took the integer path (the plane was written), the threshold has an exact integer form and sits inside
     // its own bin in integer terms: E[best] <= G_thr <= E[best+1]  (E[256] = +inf)
@@ -849,7 +849,7 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
         const hipError_t e = hipStreamWaitEvent(s, j.wait_event, 0);
         if (e != hipSuccess) return e;
     }
-    if (j.C == 3) {
+    if (j.C == 3 || j.dtype == LFA_F64) {                    // the float64-gray path (colour images, float64 images)
         static const int mm_bpi = [] { const char* e = getenv("LFA_MM_BPI"); return e ? atoi(e) : 0; }();
         const dim3 grid(mm_bpi > 0 ? mm_bpi : blocks_per_image(j, 256 * 64), j.n);
         LFA_DISPATCH_V(k_minmax_rgb, grid, dim3(256), s, j);

@@ -258,10 +258,13 @@ int ensure_workspace(LfaContext* h, int n, int H, int W, int C, int dtype, int L
     return LFA_OK;
 }
 
-int check_images(LfaContext* h, const void* images, int dtype, int n, int H, int W, int C) {
+int pixel_bytes(int dtype) { return dtype == LFA_U16 ? 2 : (dtype == LFA_F64 ? 8 : 1); }
+
+int check_images(LfaContext* h, const void* images, int dtype, int n, int H, int W, int C, bool allow_f64 = false) {
     if (!h) return fail(LFA_ERR_ARG, "null handle");
     if (!images) return fail(LFA_ERR_ARG, "null image pointer");
-    if (dtype != LFA_U8 && dtype != LFA_U16) return fail(LFA_ERR_ARG, "dtype must be LFA_U8 or LFA_U16, got %d", dtype);
+    if (dtype == LFA_F64 && !allow_f64) return fail(LFA_ERR_UNSUPPORTED, "float64 images are taken by lfa_detect_batch only");
+    if (dtype != LFA_U8 && dtype != LFA_U16 && dtype != LFA_F64) return fail(LFA_ERR_ARG, "dtype must be LFA_U8, LFA_U16 or LFA_F64, got %d", dtype);
     if (n < 1 || n > h->max_batch) return fail(LFA_ERR_ARG, "n=%d outside [1, max_batch=%d]", n, h->max_batch);
     if (H < 1 || W < 1 || H > h->max_h || W > h->max_w) return fail(LFA_ERR_ARG, "image %dx%d outside the handle's %dx%d", H, W, h->max_h, h->max_w);
     if (C != 1 && C != 3) return fail(LFA_ERR_ARG, "C must be 1 (2-D image) or 3 (colour), got %d (skimage rgb2gray: the input array must have size 3 along channel_axis)", C);
@@ -273,13 +276,13 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
                   int L, int max_strips) {
     lfa::Job j{};
     j.images = (const uint8_t*)images;
-    j.img_bytes = (int64_t)H * W * C * (dtype == LFA_U16 ? 2 : 1);
+    j.img_bytes = (int64_t)H * W * C * pixel_bytes(dtype);
     j.n = n; j.H = H; j.W = W; j.C = C; j.dtype = dtype;
     j.min_maxr = min_maxr; j.min_maxc = min_maxc; j.line_length = L;
     j.gray_variant = h->gray_variant;
     j.debug_flags = h->debug_flags;
     j.aligned16 = (((uintptr_t)images & 15) == 0 && (j.img_bytes & 15) == 0) ? 1 : 0;
-    if (C == 3 && dtype == LFA_U16) j.aligned16 = 0;         // uint16 colour: the scalar float64 paths of every kernel (rare input, kept simple)
+    if ((C == 3 && dtype == LFA_U16) || dtype == LFA_F64) j.aligned16 = 0;   // uint16 colour, float64: the scalar float64 paths of every kernel (rare inputs, kept simple)
     j.HB = (H + 63) / 64;
     j.run_cap = run_capacity(H, W, L);
     j.max_strips = max_strips;
@@ -361,8 +364,8 @@ size_t carve_workspace(Workspace& w, unsigned char* base, size_t capacity, int n
 // either need memory or are choices between paths with identical results).
 int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
                 int L, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
-                LfaRoi* out_rois, hipStream_t s, lfa::Job* job_out, bool static_ws = false, LfaRoi** ws_rois = nullptr) {
-    int rc = check_images(h, images, dtype, n, H, W, C);
+                LfaRoi* out_rois, hipStream_t s, lfa::Job* job_out, bool static_ws = false, LfaRoi** ws_rois = nullptr, bool allow_f64 = false) {
+    int rc = check_images(h, images, dtype, n, H, W, C, allow_f64);
     if (rc) return rc;
     if (H > 65535 || W > 65535) return fail(LFA_ERR_ARG, "image sides above 65535 are not supported");
     if ((long long)H * W > (1ll << 30)) return fail(LFA_ERR_UNSUPPORTED, "images above 2^30 pixels are not supported");
@@ -542,7 +545,7 @@ int lfa_detect_batch(LfaHandle h, const void* images, int dtype, int n, int H, i
                      int line_length, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
                      void* stream) {
     int rc = detect_impl(h, images, dtype, n, H, W, C, min_maxr, min_maxc, line_length, out_strips, max_strips, out_counts,
-                         out_info, nullptr, (hipStream_t)stream, nullptr);
+                         out_info, nullptr, (hipStream_t)stream, nullptr, false, nullptr, /*allow_f64=*/true);
     if (rc) return rc;
     LFA_ON_DEVICE(h->device);
     LFA_HIP(hipEventRecord(h->done_event, (hipStream_t)stream));

@@ -109,12 +109,11 @@ __device__ inline double gray_u8(uint32_t p0, uint32_t p1, uint32_t p2) {
     return fma(x1, c1, x0 * c0) + x2 * c2;
 }
 
-// the same for uint16 colour pixels (x_k = fl(pixel_k * fl(1/65535))) and the pixel of either type at index px of an image
+// the same dot product on already scaled values, for the pixel types that have no integer form: uint16 colour
+// (x_k = fl(pixel_k * fl(1/65535))), float64 colour (x_k = pixel_k: img_as_float leaves floats alone), float64 2-D (gray = pixel)
 template <int V>
-__device__ inline double gray_u16(uint32_t p0, uint32_t p1, uint32_t p2) {
-    const double inv = 1.0 / 65535.0;
+__device__ inline double gray_mix(double x0, double x1, double x2) {
     const double c0 = 0.2125, c1 = 0.7154, c2 = 0.0721;
-    const double x0 = (double)p0 * inv, x1 = (double)p1 * inv, x2 = (double)p2 * inv;
     if (V == LFA_GRAY_FMA_102) return fma(x2, c2, fma(x0, c0, x1 * c1));
     if (V == LFA_GRAY_SEQ) return (x0 * c0 + x1 * c1) + x2 * c2;
     if (V == LFA_GRAY_FMA_012) return fma(x2, c2, fma(x1, c1, x0 * c0));
@@ -122,9 +121,18 @@ __device__ inline double gray_u16(uint32_t p0, uint32_t p1, uint32_t p2) {
     if (V == LFA_GRAY_PAIR) return x0 * c0 + (x1 * c1 + x2 * c2);
     return fma(x1, c1, x0 * c0) + x2 * c2;
 }
+// gray of pixel px of an image of pixel type `dtype` with C channels (the scalar paths of the colour kernels)
 template <int V>
-__device__ inline double gray_at(const uint8_t* base, int64_t px, bool u16) {
-    if (u16) { const uint16_t* b = (const uint16_t*)base; return gray_u16<V>(b[3 * px], b[3 * px + 1], b[3 * px + 2]); }
+__device__ inline double gray_at(const uint8_t* base, int64_t px, int dtype, int C) {
+    if (dtype == LFA_U16) {
+        const uint16_t* b = (const uint16_t*)base;
+        const double inv = 1.0 / 65535.0;
+        return gray_mix<V>((double)b[3 * px] * inv, (double)b[3 * px + 1] * inv, (double)b[3 * px + 2] * inv);
+    }
+    if (dtype == LFA_F64) {
+        const double* b = (const double*)base;
+        return C == 1 ? b[px] : gray_mix<V>(b[3 * px], b[3 * px + 1], b[3 * px + 2]);
+    }
     return gray_u8<V>(base[3 * px], base[3 * px + 1], base[3 * px + 2]);
 }
 

@@ -35,13 +35,15 @@ def _engine(H, W):
     return _capi.shared_engine(_DEVICE, H, W)
 
 
-def _check_pixels(image: np.ndarray) -> np.ndarray:
+def _check_pixels(image: np.ndarray, allow_float64=False) -> np.ndarray:
     if image.dtype == np.uint8 or image.dtype == np.uint16:
         return image
     if image.dtype.kind in "if" and np.any(image < 0):
         # skimage.exposure._assert_non_negative (exposure.py:603-608)
         raise ValueError("Image Correction methods work correctly only on images with non-negative values. "
                          "Use skimage.exposure.rescale_intensity.")
+    if allow_float64 and image.dtype == np.float64:
+        return image
     raise NotImplementedError(f"pixel dtype {image.dtype}: the HIP path takes uint8 and uint16 images "
                               "(what cv2.imread / tifffile hand the reference, detection.py:454)")
 
@@ -59,10 +61,13 @@ def detect_lateral_flow_tests(image, line_length=10):
         raise ValueError("Invalid image dimensions. Only 2D and 3D images are supported.")
     if image.size == 0:
         raise ValueError("empty image")
-    _check_pixels(image)
+    _check_pixels(image, allow_float64=True)
     H, W = image.shape[0], image.shape[1]
     eng = _engine(H, W)
-    strips, _info = eng.detect(image[None], int(min_maxr), int(min_maxc), int(line_length))
+    strips, info = eng.detect(np.ascontiguousarray(image)[None], int(min_maxr), int(min_maxc), int(line_length))
+    if info["status"][0] & 4:
+        raise NotImplementedError("float image whose pixel (0, 0) is foreground: the reference compares float box means here "
+                                  "(detection.py:76-81), which the HIP path does not restate")
     return [image[int(s["minr"]):int(s["maxr"]), int(s["minc"]):int(s["maxc"])] for s in strips[0]]
 
 

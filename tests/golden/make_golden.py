@@ -319,6 +319,14 @@ def skimage_detect_cases():
     c16 = (c8.astype(np.uint16) << 8) | rng.integers(0, 256, size=c8.shape).astype(np.uint16)
     cases.append(("synth_rgb16_192x256", np.ascontiguousarray(c16), *gui(c16[:, :, 0]), 10))
     cases.append(("constant_rgb16", np.full((40, 44, 3), 3000, np.uint16), 20, 3, 10))
+    # float64 images: what rgb2gray / img_as_float hand on (2-D and colour), values above 1, a constant image
+    cf = c8 / 255.0 + rng.random(c8.shape) * 1e-3
+    cases.append(("synth_rgb_f64_192x256", np.ascontiguousarray(cf), *gui(c8[:, :, 0]), 10))
+    gf = np.ascontiguousarray(cf @ np.array([0.2125, 0.7154, 0.0721]))
+    cases.append(("synth_gray_f64_192x256", gf, *gui(c8[:, :, 0]), 10))
+    cases.append(("synth_gray_f64_times_3p7", np.ascontiguousarray(c8[:, :, 1] * 3.7), *gui(c8[:, :, 0]), 10))
+    cases.append(("u16_as_float_256", synth_u16(256, 256, 6, 5) / 65535.0, 40, 4, 5))
+    cases.append(("constant_f64", np.full((40, 44), 0.25), 20, 3, 10))
     return cases
 
 
