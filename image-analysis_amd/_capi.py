@@ -348,7 +348,7 @@ class Engine:
                     ms = min(1024, ms * 4)
                     continue
                 break
-            if (inf["status"] & ~4).any():         # (bit 2: float image with a foreground corner -- the caller's to report, lfa.h)
+            if (inf["status"] != 0).any():
                 raise LfaError(-3, f"detect overflow (status {inf['status'].tolist()}): more than 1024 strips per image")
             cn = from_device(counts, np.int32, b1 - b0)
             st = from_device(strips, STRIP_DT, (b1 - b0) * ms).reshape(b1 - b0, ms)

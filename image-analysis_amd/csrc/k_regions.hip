@@ -11,6 +11,7 @@
 #include "lfa_internal.h"
 #include "lfa_device.h"
 #include "lfa_regions.h"
+#include "lfa_algo.h"
 
 namespace lfa {
 
@@ -29,11 +30,42 @@ __global__ __launch_bounds__(256) void k_box_sums(Job j) {
     // is `mean > 0`, which always holds: the box contains the component, and every pixel of a component is above a
     // non-negative threshold, hence non-zero.  So the box pass runs only for images whose corner pixel is foreground.
     if (j.info[img].label00 == 0) return;
-    if (j.dtype == LFA_F64) {                                     // float box means (numpy's summation order): not implemented
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&j.info[img].status, 4);
+    const int nc = j.info[img].n_candidates;
+    if (j.dtype == LFA_F64) {
+        // float64 images: np.mean of the box is a float sum, whose rounding depends on numpy's order.  2-D box (a strided view
+        // reduced over both axes): numpy copies the view in C order into buffers of 8192 elements, sums each with its pairwise
+        // sum and adds the buffers up in turn; colour box reduced over (0, 1): one running sum per channel over the pixels in
+        // raster order.  (Checked against numpy 2.2 on random boxes, tests/test_cpu_boundary.py; the sums travel to k_finalize
+        // as bit patterns in cand_sum.)  One thread per candidate: a rare case -- only images whose corner pixel is foreground.
+        if (threadIdx.x != 0) return;
+        const double* fb = (const double*)(j.images + (int64_t)img * j.img_bytes);
+        for (int ci = blockIdx.x; ci < nc; ci += gridDim.x) {
+            const Box bx = cand_box(j, rbase, j.root_of_label[rbase + j.cand[cbase + ci] - 1]);
+            const int w = bx.cc - bx.minc, h = bx.cr - bx.minr;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            if (j.C == 1) {
+                const int64_t n = (int64_t)h * w;
+                const double* org = fb + (int64_t)bx.minr * j.W + bx.minc;
+                const int W = j.W;
+                auto at = [org, w, W](int i) -> double { const int y = i / w; return org[(int64_t)y * W + (i - y * w)]; };
+                for (int64_t o = 0; o < n; o += 8192) {
+                    const int m = (int)(n - o < 8192 ? n - o : 8192);
+                    const int o32 = (int)o;
+                    a0 = a0 + np_pairwise([&](int i) { return at(o32 + i); }, 0, m);
+                }
+            } else {
+                for (int y = bx.minr; y < bx.cr; ++y)
+                    for (int x = bx.minc; x < bx.cc; ++x) {
+                        const double* px = fb + ((int64_t)y * j.W + x) * 3;
+                        a0 = a0 + px[0]; a1 = a1 + px[1]; a2 = a2 + px[2];
+                    }
+            }
+            unsigned long long* cs = j.cand_sum + (cbase + ci) * 3;
+            cs[0] = (unsigned long long)__double_as_longlong(a0); cs[1] = (unsigned long long)__double_as_longlong(a1);
+            cs[2] = (unsigned long long)__double_as_longlong(a2);
+        }
         return;
     }
-    const int nc = j.info[img].n_candidates;
     const uint8_t* base = j.images + (int64_t)img * j.img_bytes;
     __shared__ unsigned long long part[4][3];
     __shared__ unsigned int wrow[kWinRowsLds];                    // window row sums of this candidate
@@ -161,11 +193,15 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
                 const double cnt = (double)((long long)(bx.cr - bx.minr) * (long long)(bx.cc - bx.minc));
                 const unsigned long long* cs = j.cand_sum + (cbase + ci) * 3;
                 double mean;
+                const bool f64 = j.dtype == LFA_F64;                  // (float images: the sums are float64 bit patterns, k_box_sums)
+                const double s0 = f64 ? __longlong_as_double((long long)cs[0]) : (double)cs[0];
                 if (j.C == 3) {
-                    const double m0 = (double)cs[0] / cnt, m1 = (double)cs[1] / cnt, m2 = (double)cs[2] / cnt;
+                    const double s1 = f64 ? __longlong_as_double((long long)cs[1]) : (double)cs[1];
+                    const double s2 = f64 ? __longlong_as_double((long long)cs[2]) : (double)cs[2];
+                    const double m0 = s0 / cnt, m1 = s1 / cnt, m2 = s2 / cnt;
                     mean = ((m0 + m1) + m2) / 3.0;
                 } else {
-                    mean = (double)cs[0] / cnt;
+                    mean = s0 / cnt;
                 }
                 ok = mean > bg;
             }

@@ -205,8 +205,9 @@ int lfa_profile_lut_batch(LfaHandle h, const void* images, int dtype, int n, int
 #define LFA_E_F64 6
 /* float64 IMAGES (2-D or colour, non-negative values) are taken by lfa_detect_batch only, as pixel dtype LFA_F64: gray is the
  * pixel itself (2-D) or rgb @ coeffs without the 1/255 scaling (colour), everything downstream is the colour path's float64
- * arithmetic (skimage: img_as_float leaves floats alone, adjust_gamma uses scale 1).  One case is not implemented and sets bit 2
- * of LfaImageInfo.status: a float image whose pixel (0,0) belongs to a component (the reference then compares float box means). */
+ * arithmetic (skimage: img_as_float leaves floats alone, adjust_gamma uses scale 1).  When pixel (0,0) belongs to a component
+ * the reference compares float box means: those sums follow numpy's order (2-D: pairwise over C-order buffers of 8192 elements;
+ * colour: one running sum per channel), k_regions.hip. */
 #define LFA_F64 LFA_E_F64
 int lfa_profile_any_batch(LfaHandle h, const void* regions, int elem_type, int n, int H, int W, int C, const LfaRoi* rois,
                           int n_rois, int inverse, int range, double* out_profiles, int profile_stride, LfaPeaks* out_peaks,

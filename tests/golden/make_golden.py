@@ -327,6 +327,14 @@ def skimage_detect_cases():
     cases.append(("synth_gray_f64_times_3p7", np.ascontiguousarray(c8[:, :, 1] * 3.7), *gui(c8[:, :, 0]), 10))
     cases.append(("u16_as_float_256", synth_u16(256, 256, 6, 5) / 65535.0, 40, 4, 5))
     cases.append(("constant_f64", np.full((40, 44), 0.25), 20, 3, 10))
+    # ... with a foreground corner: the region test compares float box means (numpy's summation order)
+    # (label(0,0) is 1 here, so only boxes whose mean exceeds 1 pass: values well above 1, and values scattered around 1)
+    ef = e * 0.731 + rng.random(e.shape) * 1e-2
+    cases.append(("edges_f64", np.ascontiguousarray(ef), 100, 5, 10))
+    cases.append(("edges_f64_mm0", np.ascontiguousarray(ef), 0, 0, 10))
+    cases.append(("edges_rgb_f64", np.ascontiguousarray(np.stack([ef, ef * 0.98 + 0.004, ef * 1.01], axis=2)), 100, 5, 10))
+    en = e / 215.0 + rng.random(e.shape) * 1e-2                               # bright areas ~ 0.93 .. 1.12
+    cases.append(("edges_f64_near_one", np.ascontiguousarray(en), 20, 3, 10))
     return cases
 
 

@@ -228,3 +228,47 @@ def test_shard_and_gather_world_size_2_gloo(tmp_path):
              for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_numpy_float_box_sum_order_is_what_k_box_sums_restates():
+    """k_regions.hip (float64 images, foreground corner): np.mean of a strided 2-D box = pairwise sums over C-order buffers of
+    8192 elements added up in turn; of a colour box over axes (0, 1) = one running sum per channel in raster order.  Pure numpy:
+    if a numpy upgrade changes this order, this test says so before the GPU parity tests do."""
+    def pw(a):
+        n = len(a)
+        if n < 8:
+            r = 0.0
+            for x in a:
+                r = r + x
+            return r
+        if n <= 128:
+            r = [a[i] for i in range(8)]
+            lim = n - n % 8
+            for i in range(8, lim, 8):
+                for k in range(8):
+                    r[k] = r[k] + a[i + k]
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+            for i in range(lim, n):
+                res = res + a[i]
+            return res
+        n2 = n // 2
+        n2 -= n2 % 8
+        return pw(a[:n2]) + pw(a[n2:])
+
+    rng = np.random.default_rng(8192)
+    img = rng.random((500, 300))
+    for h, w in ((1, 1), (7, 5), (120, 12), (130, 51), (400, 40), (33, 250)):
+        v = img[11:11 + h, 7:7 + w]
+        flat = [float(x) for x in v.ravel()]
+        acc = 0.0
+        for i in range(0, len(flat), 8192):
+            acc = acc + pw(flat[i:i + 8192])
+        assert np.float64(acc / (h * w)).tobytes() == np.float64(np.mean(v)).tobytes(), (h, w)
+    img3 = rng.random((200, 100, 3))
+    for h, w in ((1, 1), (9, 4), (120, 12), (150, 51)):
+        v = img3[5:5 + h, 3:3 + w, :]
+        a = np.zeros(3)
+        for y in range(h):
+            for x in range(w):
+                a = a + v[y, x]
+        assert (a / (h * w)).tobytes() == np.mean(v, axis=(0, 1)).tobytes(), (h, w)

@@ -111,8 +111,8 @@ def test_region_dtype_fuzz():
 
 
 def test_float64_image_detect_fuzz():
-    """float64 images, 2-D and colour (what rgb2gray / img_as_float hand on): crops against the oracle; a float image whose
-    corner pixel is foreground is the one documented gap (NotImplementedError)."""
+    """float64 images, 2-D and colour (what rgb2gray / img_as_float hand on): crops against the oracle, including images whose
+    corner pixel is foreground (the region test then compares float box means in numpy's summation order)."""
     import image_analysis_amd.detection as detection
     from oracle import lfa_oracle as O
     rng = np.random.default_rng(4242)
@@ -125,17 +125,13 @@ def test_float64_image_detect_fuzz():
             for _ in range(int(rng.integers(1, 4))):
                 c0 = int(rng.integers(0, W - 8)); w = int(rng.integers(3, 9)); r0 = int(rng.integers(0, H // 2)); h = int(rng.integers(12, H // 2))
                 im[r0:r0 + h, c0:c0 + w] = rng.random(im[r0:r0 + h, c0:c0 + w].shape) * 0.3 + 0.6
-            if it in (5, 6):
-                im[0:40, 0:6] = 0.9                                  # foreground corner
+            if it in (5, 6, 9, 10):
+                im[0:40, 0:6] = 0.9 + rng.random(im[0:40, 0:6].shape) * 0.05      # foreground corner
             if it % 4 == 3:
                 im *= 7.5                                            # values above 1: adjust_gamma's scale stays 1
             detection.min_maxr, detection.min_maxc = int(rng.integers(0, 40)), int(rng.integers(0, 8))
             d = O.detect_debug(im, detection.min_maxr, detection.min_maxc, 10)
-            if d["background"] != 0:
-                with pytest.raises(NotImplementedError):
-                    detection.detect_lateral_flow_tests(im)
-                gaps += 1
-                continue
+            gaps += d["background"] != 0
             got = detection.detect_lateral_flow_tests(im)
             want = [im[a:b, c:e] for a, b, c, e in d["strips"]]
             assert len(got) == len(want), it
@@ -148,4 +144,4 @@ def test_float64_image_detect_fuzz():
             detection.detect_lateral_flow_tests(np.zeros((32, 32), np.float32))
     finally:
         detection.min_maxr, detection.min_maxc = 0, 0
-    assert found >= 10 and gaps >= 1
+    assert found >= 10 and gaps >= 2
