@@ -234,6 +234,15 @@ def analyze_batch(images, line_length=10, max_batch=16, device=None, max_strips=
     images = np.asanyarray(images)
     if images.ndim not in (3, 4) or (images.ndim == 4 and images.shape[-1] != 3):
         raise ValueError("expected a batch (n,H,W) or (n,H,W,3)")
+    if images.dtype == np.float64:
+        # float64 images: the batched C call takes integer pixels; detect and the profiles run per image / per crop
+        # (lfa_detect_batch with LFA_F64, lfa_profile_any_batch) -- same results, no batching across images
+        _check_pixels(images, allow_float64=True)
+        out = []
+        for img in images:
+            crops = detect_lateral_flow_tests(img, line_length)
+            out.append([(c, *image_analysis(c, False)) for c in crops])
+        return out
     _check_pixels(images)
     if devices is not None:
         res = _analyze_sharded(images, [int(d) for d in devices], int(line_length), int(max_batch), int(max_strips))

@@ -145,3 +145,24 @@ def test_float64_image_detect_fuzz():
     finally:
         detection.min_maxr, detection.min_maxc = 0, 0
     assert found >= 10 and gaps >= 2
+
+
+def test_analyze_batch_of_float64_images():
+    import image_analysis_amd.detection as detection
+    from image_analysis_amd.synth import synth_rgb
+    from oracle import lfa_oracle as O
+    c8 = synth_rgb(192, 256, 4, 31)
+    ims = np.stack([O.rgb2gray(c8), O.rgb2gray(synth_rgb(192, 256, 4, 32))])
+    mm_c = int(256 / 40)
+    detection.min_maxr, detection.min_maxc = mm_c * 20, mm_c
+    try:
+        got = detection.analyze_batch(ims)
+        for im, res in zip(ims, got):
+            want = O.analyze_image(im)
+            assert len(res) == len(want) > 0
+            for (crop, prof, peaks), (wp, wk) in zip(res, want):
+                assert prof.tobytes() == wp.tobytes()
+                assert [(s, e) for s, e, _ in peaks] == [(s, e) for s, e, _ in wk]
+                assert all(np.float64(a).tobytes() == np.float64(b).tobytes() for (_, _, a), (_, _, b) in zip(peaks, wk))
+    finally:
+        detection.min_maxr, detection.min_maxc = 0, 0
