@@ -29,36 +29,55 @@ __device__ __forceinline__ int reflect_half(int i, int n) {         // scipy 're
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
+constexpr int kLocalRows = 4;                                        // rows one wave filters per step (kLocalRows + 2 loads in flight per lane)
+
 __global__ __launch_bounds__(256) void k_lines_local(LinesJob j) {
     const int img = blockIdx.y;
     const int64_t npix = (int64_t)j.H * j.W;
-    const double* g = j.g + (int64_t)img * npix;
-    uint16_t* u = j.u + (int64_t)img * npix;
+    const double* __restrict__ g = j.g + (int64_t)img * npix;
+    uint16_t* __restrict__ u = j.u + (int64_t)img * npix;
     int lo = 65535, hi = 0;
     int over = 0;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
-        const int ym = reflect_half(y - 1, j.H), yp = reflect_half(y + 1, j.H);
-        const int xm = reflect_half(x - 1, j.W), xp = reflect_half(x + 1, j.W);
-        auto col = [&](int xx) -> double {                            // axis 0 first (scipy.ndimage.gaussian_filter)
-            double t = g[(int64_t)y * j.W + xx] * j.w0;
-            t += (g[(int64_t)ym * j.W + xx] + g[(int64_t)yp * j.W + xx]) * j.w1;
-            return t;
-        };
-        double t = col(x) * j.w0;
-        t += (col(xm) + col(xp)) * j.w1;
-        const double gv = g[p];
-        const double xg = (t - 0.0 > 0.0) ? gv * 1.0 : gv * 0.0;      // image_copy * (thresholded_image > 0), detection.py:170
-        const double s = sqrt(xg / 1.0) * 1.0 * 1.0;                  // ((image / scale) ** gamma) * scale * gain
-        if (s > 1.0 || s < -1.0) over = 1;                            // img_as_uint refuses such an image
-        double v = rint(s * 65535.0);
-        v = v < 0.0 ? 0.0 : (v > 65535.0 ? 65535.0 : v);
-        const int q = (int)v;
-        u[p] = (uint16_t)q;
-        lo = min(lo, q); hi = max(hi, q);
+    const int lane = threadIdx.x & 63;
+    // A wave takes a patch of kLocalRows rows by 64 columns per step and writes the 62 columns in its middle: every lane
+    // filters its own column along axis 0 (a sliding window over kLocalRows + 2 loads, all issued before the first use) and
+    // takes the two neighbouring column results from the lanes beside it, so lanes 0 and 63 only supply their column.  No
+    // lane ever computes a neighbour's column itself (a branch that one lane of every wave would take costs the whole wave
+    // its latency), and 'reflect' at the frame's edges is the clamp of the column / row index (overshoot 1).
+    const int ncg = (j.W + 61) / 62, nrg = (j.H + kLocalRows - 1) / kLocalRows;
+    const int64_t tasks = (int64_t)ncg * nrg;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t t = wave; t < tasks; t += nwaves) {
+        const int rg = (int)(t / ncg), cg = (int)(t - (int64_t)rg * ncg);
+        const int x = cg * 62 + lane - 1, xc = reflect_half(x, j.W);
+        const int y0 = rg * kLocalRows;
+        double v[kLocalRows + 2];
+#pragma unroll
+        for (int k = 0; k < kLocalRows + 2; ++k) v[k] = g[(int64_t)reflect_half(y0 - 1 + k, j.H) * j.W + xc];
+        const bool writes = lane >= 1 && lane <= 62 && x < j.W;
+#pragma unroll
+        for (int r = 0; r < kLocalRows; ++r) {
+            if (y0 + r >= j.H) break;                                 // (wave-uniform)
+            double c0 = v[r + 1] * j.w0;                              // axis 0 first (scipy.ndimage.gaussian_filter)
+            c0 += (v[r] + v[r + 2]) * j.w1;
+            const double cm = __shfl_up(c0, 1), cp = __shfl_down(c0, 1);
+            double tl = c0 * j.w0;
+            tl += (cm + cp) * j.w1;
+            const double gv = v[r + 1];
+            const double xg = (tl - 0.0 > 0.0) ? gv * 1.0 : gv * 0.0; // image_copy * (thresholded_image > 0), detection.py:170
+            const double sq = sqrt(xg / 1.0) * 1.0 * 1.0;             // ((image / scale) ** gamma) * scale * gain
+            double q = rint(sq * 65535.0);
+            q = q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q);
+            const int qi = (int)q;
+            if (writes) {
+                if (sq > 1.0 || sq < -1.0) over = 1;                  // img_as_uint refuses such an image
+                u[(int64_t)(y0 + r) * j.W + x] = (uint16_t)qi;
+                lo = min(lo, qi); hi = max(hi, qi);
+            }
+        }
     }
     lo = wave_min_i32(lo); hi = wave_max_i32(hi);
-    if ((threadIdx.x & 63) == 0) { atomicMin(&j.info[img].umin, lo); atomicMax(&j.info[img].umax, hi); }
+    if ((threadIdx.x & 63) == 0 && hi >= lo) { atomicMin(&j.info[img].umin, lo); atomicMax(&j.info[img].umax, hi); }
     if (over) atomicOr(&j.info[img].status, 2);
 }
 
@@ -165,44 +184,76 @@ __global__ __launch_bounds__(256) void k_clahe_tiles(LinesJob j) {
 }
 
 // ---- stage 5: bilinear blend of the four neighbouring tile maps (_adapthist.py:176-210) ------------------------------------
+constexpr int kBlendRows = 64;                                       // a block blends a patch of kBlendRows rows by 256 columns
+
 __global__ __launch_bounds__(256) void k_clahe_blend(LinesJob j) {
-    __shared__ uint32_t sh[16384];                                       // level histogram of this block's pixels
-    for (int k = threadIdx.x; k < 16384; k += 256) sh[k] = 0u;
-    __syncthreads();
+    // level histogram of this block's pixels: 16-bit counters, two per word (a block sees kBlendRows * 256 = 16 384 pixels),
+    // 32 KiB instead of 64 so that five blocks share a CU instead of two
+    __shared__ uint32_t sh[8192];
+    __shared__ double s_cy[kBlendRows];                                  // per row of the patch: weight of the lower tile row,
+    __shared__ int s_ty[kBlendRows][2];                                  // offsets of the two tile rows' maps
+    for (int k = threadIdx.x; k < 8192; k += 256) sh[k] = 0u;
     const int img = blockIdx.y;
     const int64_t npix = (int64_t)j.H * j.W;
-    const uint16_t* u = j.u + (int64_t)img * npix;
-    const uint8_t* lut = j.binlut + (int64_t)img * 65536;
-    const int32_t* maps = j.maps + (int64_t)img * j.nty * j.ntx * 256;
-    uint16_t* lv = j.levels + (int64_t)img * npix;
+    const uint16_t* __restrict__ u = j.u + (int64_t)img * npix;
+    const uint8_t* __restrict__ lut = j.binlut + (int64_t)img * 65536;
+    const int32_t* __restrict__ maps = j.maps + (int64_t)img * j.nty * j.ntx * 256;
+    uint16_t* __restrict__ lv = j.levels + (int64_t)img * npix;
+    const int ncb = (j.W + 255) / 256;
+    const int rb = blockIdx.x / ncb, cb = blockIdx.x - rb * ncb;
+    const int y0 = rb * kBlendRows, x = cb * 256 + threadIdx.x;
+    const int rows = min(kBlendRows, j.H - y0);
+    // the divisions of _adapthist.py:176-210 are per row and per column, not per pixel: one thread per row of the patch
+    // computes the row's, every thread its own column's
+    if ((int)threadIdx.x < rows) {
+        const int py = y0 + threadIdx.x + j.sy, by = py / j.kh;
+        s_cy[threadIdx.x] = (double)(py % j.kh) / (double)j.kh;
+        s_ty[threadIdx.x][0] = min(max(by - 1, 0), j.nty - 1) * j.ntx * 256;
+        s_ty[threadIdx.x][1] = min(max(by, 0), j.nty - 1) * j.ntx * 256;
+    }
+    __syncthreads();
     int lo = 65535, hi = 0;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
-        const int py = y + j.sy, px = x + j.sx;
-        const int by = py / j.kh, bx = px / j.kw;
-        const double cy = (double)(py % j.kh) / (double)j.kh, cx = (double)(px % j.kw) / (double)j.kw;
-        const int bin = lut[u[p]];
-        float res = 0.0f;
+    if (x < j.W) {
+        const int px = x + j.sx, bx = px / j.kw;
+        const double cx1 = (double)(px % j.kw) / (double)j.kw, cx0 = 1.0 - cx1;
+        const int tx0 = min(max(bx - 1, 0), j.ntx - 1) * 256, tx1 = min(max(bx, 0), j.ntx - 1) * 256;
+        for (int r0 = 0; r0 < rows; r0 += 4) {                           // four rows per step: their loads are issued together
+            int bin[4], m[4][4];
 #pragma unroll
-        for (int e0 = 0; e0 < 2; ++e0) {
+            for (int k = 0; k < 4; ++k) bin[k] = u[(int64_t)(y0 + min(r0 + k, rows - 1)) * j.W + x];
 #pragma unroll
-            for (int e1 = 0; e1 < 2; ++e1) {
-                const int ty = min(max(by + e0 - 1, 0), j.nty - 1), tx = min(max(bx + e1 - 1, 0), j.ntx - 1);
-                const double coeff = (e1 ? cx : 1.0 - cx) * (e0 ? cy : 1.0 - cy);
-                const double m = (double)maps[((int64_t)ty * j.ntx + tx) * 256 + bin];
-                res = res + (float)(m * coeff);
+            for (int k = 0; k < 4; ++k) bin[k] = lut[bin[k]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = min(r0 + k, rows - 1), t0 = s_ty[r][0], t1 = s_ty[r][1];
+                m[k][0] = maps[t0 + tx0 + bin[k]]; m[k][1] = maps[t0 + tx1 + bin[k]];
+                m[k][2] = maps[t1 + tx0 + bin[k]]; m[k][3] = maps[t1 + tx1 + bin[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (r0 + k >= rows) break;
+                const double cy1 = s_cy[r0 + k], cy0 = 1.0 - cy1;
+                float res = 0.0f;                                        // the reference's float32 accumulator, edge order (0,0) (0,1) (1,0) (1,1)
+                res = res + (float)((double)m[k][0] * (cx0 * cy0));
+                res = res + (float)((double)m[k][1] * (cx1 * cy0));
+                res = res + (float)((double)m[k][2] * (cx0 * cy1));
+                res = res + (float)((double)m[k][3] * (cx1 * cy1));
+                const int q = (int)res;                                  // result.astype(uint16): truncation
+                lv[(int64_t)(y0 + r0 + k) * j.W + x] = (uint16_t)q;
+                atomicAdd(&sh[(q & 16383) >> 1], (q & 1) ? 0x10000u : 1u);
+                lo = min(lo, q); hi = max(hi, q);
             }
         }
-        const int q = (int)res;                                          // result.astype(uint16): truncation
-        lv[p] = (uint16_t)q;
-        atomicAdd(&sh[q & 16383], 1u);
-        lo = min(lo, q); hi = max(hi, q);
     }
     lo = wave_min_i32(lo); hi = wave_max_i32(hi);
     if ((threadIdx.x & 63) == 0 && hi >= lo) { atomicMin(&j.info[img].cmin, lo); atomicMax(&j.info[img].cmax, hi); }
     __syncthreads();
     uint32_t* gh = j.lhist + (int64_t)img * 16384;
-    for (int k = threadIdx.x; k < 16384; k += 256) if (sh[k]) atomicAdd(&gh[k], sh[k]);
+    for (int k = threadIdx.x; k < 8192; k += 256) {
+        const uint32_t w = sh[k];
+        if (w & 0xffffu) atomicAdd(&gh[2 * k], w & 0xffffu);
+        if (w >> 16) atomicAdd(&gh[2 * k + 1], w >> 16);
+    }
 }
 
 // ---- stage 6: percentiles, the float value of every level, classes of equal value -----------------------------------------
@@ -303,33 +354,60 @@ __device__ __forceinline__ void ccl_union(int32_t* parent, int a, int b) {
 }
 
 __global__ __launch_bounds__(256) void k_ccl_init(LinesJob j) {
+    __shared__ __align__(16) uint16_t s_cls[16384];                                    // the image's class table: the gather below stays on the CU
     const int img = blockIdx.y;
     const int64_t npix = (int64_t)j.H * j.W;
-    int32_t* parent = j.parent + (int64_t)img * npix;
-    int4* bbox = (int4*)(j.bbox + (int64_t)img * npix * 4);
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        parent[p] = (int)p;
-        const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
-        bbox[p] = make_int4(y, x, y + 1, x + 1);                         // a root starts from its own pixel; the others add theirs
+    int32_t* __restrict__ parent = j.parent + (int64_t)img * npix;
+    int4* __restrict__ bbox = (int4*)(j.bbox + (int64_t)img * npix * 4);
+    const uint16_t* __restrict__ lv = j.levels + (int64_t)img * npix;
+    uint16_t* __restrict__ cimg = j.cimg + (int64_t)img * npix;
+    {
+        const uint4* src = (const uint4*)(j.cls + (int64_t)img * 16384);
+        uint4* dst = (uint4*)s_cls;
+        for (int k = threadIdx.x; k < 2048; k += 256) dst[k] = src[k];
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < npix; p0 += 4 * stride) {
+        int l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int64_t p = p0 + k * stride; l[k] = p < npix ? lv[p] : 0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t p = p0 + k * stride;
+            if (p >= npix) break;
+            const uint16_t c = s_cls[l[k] & 16383];
+            cimg[p] = c;                                                 // the class image: what the labelling compares
+            parent[p] = c ? (int)p : -1;                                 // background takes no part
+            if (c) {
+                const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
+                bbox[p] = make_int4(y, x, y + 1, x + 1);                 // a root starts from its own pixel; the others add theirs
+            }
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void k_ccl_merge(LinesJob j) {
     const int img = blockIdx.y;
     const int64_t npix = (int64_t)j.H * j.W;
-    const uint16_t* lv = j.levels + (int64_t)img * npix;
-    const uint16_t* cls = j.cls + (int64_t)img * 16384;
+    const uint16_t* __restrict__ cimg = j.cimg + (int64_t)img * npix;
     int32_t* parent = j.parent + (int64_t)img * npix;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
-        const uint16_t c = cls[lv[p] & 16383];
+        const uint16_t c = cimg[p];
         if (!c) continue;
-        if (x > 0 && cls[lv[p - 1] & 16383] == c) ccl_union(parent, (int)p, (int)p - 1);
-        if (y > 0) {
-            const int64_t q = p - j.W;
-            if (cls[lv[q] & 16383] == c) ccl_union(parent, (int)p, (int)q);
-            if (x > 0 && cls[lv[q - 1] & 16383] == c) ccl_union(parent, (int)p, (int)q - 1);
-            if (x + 1 < j.W && cls[lv[q + 1] & 16383] == c) ccl_union(parent, (int)p, (int)q + 1);
+        const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
+        const int64_t q = p - j.W;
+        const bool hasl = x > 0, hasu = y > 0, hasr = x + 1 < j.W;
+        const uint16_t cl = hasl ? cimg[p - 1] : (uint16_t)0, cu = hasu ? cimg[q] : (uint16_t)0;
+        const uint16_t cul = (hasu && hasl) ? cimg[q - 1] : (uint16_t)0, cur = (hasu && hasr) ? cimg[q + 1] : (uint16_t)0;
+        // the pixel joins its left and upper neighbours; a diagonal one only when no edge another pixel makes already
+        // links it (the upper pixel joins its own left neighbour, the upper right one joins the upper one, the left pixel
+        // joins the upper left one): the components are the same, with fewer walks to a root
+        if (cl == c) ccl_union(parent, (int)p, (int)p - 1);
+        if (cu == c) ccl_union(parent, (int)p, (int)q);
+        else {
+            if (cul == c && cl != c) ccl_union(parent, (int)p, (int)q - 1);
+            if (cur == c) ccl_union(parent, (int)p, (int)q + 1);
         }
     }
 }
@@ -337,8 +415,6 @@ __global__ __launch_bounds__(256) void k_ccl_merge(LinesJob j) {
 __global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
     const int img = blockIdx.y;
     const int64_t npix = (int64_t)j.H * j.W;
-    const uint16_t* lv = j.levels + (int64_t)img * npix;
-    const uint16_t* cls = j.cls + (int64_t)img * 16384;
     int32_t* parent = j.parent + (int64_t)img * npix;
     int32_t* bbox = j.bbox + (int64_t)img * npix * 4;
     const int lane = threadIdx.x & 63;
@@ -350,14 +426,12 @@ __global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
         int r = -1, y = 0, x = 0;
         bool need = false;
         if (p < npix) {
-            if (!cls[lv[p] & 16383]) parent[p] = -1;                     // background
-            else {
-                r = ccl_find(parent, (int)p);
-                if (r != (int)p) {                                       // (most components of a CLAHE'd frame are single pixels)
-                    parent[p] = r;                                       // (others only ever point to smaller indices)
-                    y = (int)((uint32_t)p / (uint32_t)j.W); x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);
-                    need = true;
-                }
+            const int up = parent[p];                                    // (-1: background, k_ccl_init)
+            if (up >= 0 && up != (int)p) {                               // (most components of a CLAHE'd frame are single pixels)
+                r = ccl_find(parent, up);
+                parent[p] = r;                                           // (others only ever point to smaller indices)
+                y = (int)((uint32_t)p / (uint32_t)j.W); x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);
+                need = true;
             }
         }
         unsigned long long todo = __ballot(need);
@@ -385,15 +459,24 @@ __global__ __launch_bounds__(256) void k_ccl_collect(LinesJob j) {
     const double min_area = (double)j.W * ((double)j.H * 0.0065), max_area = (double)j.W * ((double)j.H * 0.04);   // :159-160
     int32_t* cand = j.cand + (int64_t)img * j.cap * 3;
     uint32_t roots = 0;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        if (parent[p] != (int)p) continue;
-        ++roots;
-        const int minr = bbox[4 * p], minc = bbox[4 * p + 1], maxr = bbox[4 * p + 2], maxc = bbox[4 * p + 3];
-        const int64_t area = (int64_t)(maxc - minc) * (maxr - minr);
-        // wider than tall and min_area < area < max_area: the box is widened to the whole image width and kept (:193-200)
-        if ((maxc - minc) > (maxr - minr) && (double)area > min_area && (double)area < max_area) {
-            const int k = atomicAdd(&j.info[img].n_boxes, 1);
-            if (k < j.cap) { cand[3 * k] = (int)p; cand[3 * k + 1] = minr; cand[3 * k + 2] = maxr; }
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < npix; p0 += 4 * stride) {
+        int par[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int64_t p = p0 + k * stride; par[k] = p < npix ? parent[p] : -1; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t p = p0 + k * stride;
+            if (par[k] != (int)p || p >= npix) continue;
+            ++roots;
+            const int4 b = ((const int4*)bbox)[p];
+            const int minr = b.x, minc = b.y, maxr = b.z, maxc = b.w;
+            const int64_t area = (int64_t)(maxc - minc) * (maxr - minr);
+            // wider than tall and min_area < area < max_area: the box is widened to the whole image width and kept (:193-200)
+            if ((maxc - minc) > (maxr - minr) && (double)area > min_area && (double)area < max_area) {
+                const int k2 = atomicAdd(&j.info[img].n_boxes, 1);
+                if (k2 < j.cap) { cand[3 * k2] = (int)p; cand[3 * k2 + 1] = minr; cand[3 * k2 + 2] = maxr; }
+            }
         }
     }
     roots = wave_sum_u32(roots);
@@ -432,7 +515,7 @@ hipError_t launch_lines(const LinesJob& j, LfaLineBox* out, int32_t* counts, int
     LFA_LAUNCH("k_lines_local", k_lines_local, grid, blk, 0, s, j);
     LFA_LAUNCH("k_lines_binlut", k_lines_binlut, dim3(16, j.n), blk, 0, s, j);
     LFA_LAUNCH("k_clahe_tiles", k_clahe_tiles, dim3(j.nty * j.ntx, j.n), blk, 0, s, j);
-    LFA_LAUNCH("k_clahe_blend", k_clahe_blend, grid, blk, 0, s, j);
+    LFA_LAUNCH("k_clahe_blend", k_clahe_blend, dim3(((j.W + 255) / 256) * ((j.H + kBlendRows - 1) / kBlendRows), j.n), blk, 0, s, j);
     LFA_LAUNCH("k_lines_levels", k_lines_levels, dim3(j.n), dim3(1024), 0, s, j);
     LFA_LAUNCH("k_ccl_init", k_ccl_init, grid, blk, 0, s, j);
     LFA_LAUNCH("k_ccl_merge", k_ccl_merge, grid, blk, 0, s, j);

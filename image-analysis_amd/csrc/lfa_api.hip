@@ -162,13 +162,13 @@ struct LfaContext {
     int u16_thr_mean = 0, u16_thr_spread = 0;   // mean and (largest - smallest) threshold of that call
     int win_hint = 0;                      // longest analysis window of the last completed call (rows), 0 = unknown
     // detect_lines workspace (lfa_detect_lines_batch), allocated by the first call that needs it
-    Buf ln_g, ln_u, ln_binlut, ln_maps, ln_levels, ln_lhist, ln_lval, ln_cls, ln_parent, ln_bbox, ln_cand, ln_info;
+    Buf ln_g, ln_u, ln_binlut, ln_maps, ln_levels, ln_lhist, ln_lval, ln_cls, ln_cimg, ln_parent, ln_bbox, ln_cand, ln_info;
     lfa::LinesJob lines_last{};
     bool have_lines = false;
     std::vector<Buf*> all() {
         std::vector<Buf*> v = ws.all();
         v.push_back(&lut8); v.push_back(&lut16); v.push_back(&plane_stats); v.push_back(&roi_idx);
-        for (Buf* b : {&ln_g, &ln_u, &ln_binlut, &ln_maps, &ln_levels, &ln_lhist, &ln_lval, &ln_cls, &ln_parent, &ln_bbox, &ln_cand, &ln_info})
+        for (Buf* b : {&ln_g, &ln_u, &ln_binlut, &ln_maps, &ln_levels, &ln_lhist, &ln_lval, &ln_cls, &ln_cimg, &ln_parent, &ln_bbox, &ln_cand, &ln_info})
             v.push_back(b);
         return v;
     }
@@ -753,12 +753,12 @@ int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, in
     const size_t N = (size_t)n, npix = (size_t)H * W;
     if ((rc = ensure(h->ln_g, N * npix * 8)) || (rc = ensure(h->ln_u, N * npix * 2)) || (rc = ensure(h->ln_binlut, N * 65536)) ||
         (rc = ensure(h->ln_maps, N * (size_t)j.nty * j.ntx * 256 * 4)) || (rc = ensure(h->ln_levels, N * npix * 2)) ||
-        (rc = ensure(h->ln_lhist, N * 16384 * 4)) || (rc = ensure(h->ln_lval, N * 16384 * 8)) || (rc = ensure(h->ln_cls, N * 16384 * 2)) ||
+        (rc = ensure(h->ln_lhist, N * 16384 * 4)) || (rc = ensure(h->ln_lval, N * 16384 * 8)) || (rc = ensure(h->ln_cls, N * 16384 * 2)) || (rc = ensure(h->ln_cimg, N * npix * 2)) ||
         (rc = ensure(h->ln_parent, N * npix * 4)) || (rc = ensure(h->ln_bbox, N * npix * 16)) ||
         (rc = ensure(h->ln_cand, N * (size_t)j.cap * 12)) || (rc = ensure(h->ln_info, N * sizeof(LfaLinesInfo))))
         return rc;
     j.g = (const double*)h->ln_g.p; j.u = (uint16_t*)h->ln_u.p; j.binlut = (uint8_t*)h->ln_binlut.p; j.maps = (int32_t*)h->ln_maps.p;
-    j.levels = (uint16_t*)h->ln_levels.p; j.lhist = (uint32_t*)h->ln_lhist.p; j.lval = (double*)h->ln_lval.p; j.cls = (uint16_t*)h->ln_cls.p;
+    j.levels = (uint16_t*)h->ln_levels.p; j.lhist = (uint32_t*)h->ln_lhist.p; j.lval = (double*)h->ln_lval.p; j.cls = (uint16_t*)h->ln_cls.p; j.cimg = (uint16_t*)h->ln_cimg.p;
     j.parent = (int32_t*)h->ln_parent.p; j.bbox = (int32_t*)h->ln_bbox.p; j.cand = (int32_t*)h->ln_cand.p; j.info = (LfaLinesInfo*)h->ln_info.p;
     lfa::Job gj{};
     gj.images = (const uint8_t*)images;

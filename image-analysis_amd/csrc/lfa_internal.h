@@ -148,6 +148,7 @@ struct LinesJob {
     uint32_t* lhist;         // [n][16384]   histogram of levels, then its inclusive prefix
     double* lval;            // [n][16384]   final float value per level
     uint16_t* cls;           // [n][16384]   class per level (0 = background)
+    uint16_t* cimg;          // [n][H*W]     class per pixel (k_ccl_init)
     int32_t* parent;         // [n][H*W]     union-find over pixels
     int32_t* bbox;           // [n][H*W][4]  minr, minc, maxr, maxc at roots
     int32_t* cand;           // [n][cap][3]  root, minr, maxr of the boxes that pass the filter
