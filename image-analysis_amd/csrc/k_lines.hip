@@ -90,6 +90,8 @@ __global__ void k_lines_init(LinesJob j) {
         j.info[img] = z;
     }
     for (int k = t; k < 16384; k += gridDim.x * blockDim.x) j.lhist[(int64_t)img * 16384 + k] = 0u;
+    const int nmaps = j.nty * j.ntx * 256;                               // k_clahe_hist accumulates the tile histograms here
+    for (int k = t; k < nmaps; k += gridDim.x * blockDim.x) j.maps[(int64_t)img * nmaps + k] = 0;
 }
 
 // ---- stage 3: value -> CLAHE bin table --------------------------------------------------------------------------------------
@@ -118,23 +120,45 @@ __device__ __forceinline__ int reflect_pad(int i, int n) {
     return i < n ? i : period - i;
 }
 
-// ---- stage 4: one block per CLAHE tile: histogram, clip_histogram, map_histogram --------------------------------------------
+// ---- stage 4: tile histograms (kTileSlices blocks per CLAHE tile), then one block per tile: clip_histogram, map_histogram ----
+constexpr int kTileSlices = 4;
+
+__global__ __launch_bounds__(256) void k_clahe_hist(LinesJob j) {
+    __shared__ int h[256];
+    const int img = blockIdx.y, tile = blockIdx.x / kTileSlices, slice = blockIdx.x - tile * kTileSlices;
+    const int ty = tile / j.ntx, tx = tile - ty * j.ntx;
+    const int b = threadIdx.x;
+    const int64_t npix = (int64_t)j.H * j.W;
+    const uint16_t* __restrict__ u = j.u + (int64_t)img * npix;
+    const uint8_t* __restrict__ lut = j.binlut + (int64_t)img * 65536;
+    h[b] = 0;
+    __syncthreads();
+    const int y0 = j.kh / 2 + ty * j.kh - j.sy, x0 = j.kw / 2 + tx * j.kw - j.sx;   // the tile in padded coordinates (:145-146), pad removed
+    const int per = (j.kh + kTileSlices - 1) / kTileSlices;
+    const int r_lo = slice * per, r_hi = min(j.kh, r_lo + per);
+    for (int c = b; c < j.kw; c += 256) {                                // a thread keeps its column; four rows' loads go out together
+        const int xx = reflect_pad(x0 + c, j.W);
+        for (int r0 = r_lo; r0 < r_hi; r0 += 4) {
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = u[(int64_t)reflect_pad(y0 + min(r0 + k, r_hi - 1), j.H) * j.W + xx];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lut[v[k]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (r0 + k < r_hi) atomicAdd(&h[v[k]], 1);
+        }
+    }
+    __syncthreads();
+    if (h[b]) atomicAdd(&j.maps[((int64_t)img * j.nty * j.ntx + tile) * 256 + b], h[b]);
+}
+
 __global__ __launch_bounds__(256) void k_clahe_tiles(LinesJob j) {
     __shared__ int h[256];
     __shared__ int s_sum[4];
-    const int img = blockIdx.y, tile = blockIdx.x, ty = tile / j.ntx, tx = tile % j.ntx;
+    const int img = blockIdx.y, tile = blockIdx.x;
     const int b = threadIdx.x;
-    const int64_t npix = (int64_t)j.H * j.W;
-    const uint16_t* u = j.u + (int64_t)img * npix;
-    const uint8_t* lut = j.binlut + (int64_t)img * 65536;
-    h[b] = 0;
-    __syncthreads();
-    const int y0 = j.kh / 2 + ty * j.kh, x0 = j.kw / 2 + tx * j.kw;       // padded coordinates of the tile (:145-146)
     const int n_el = j.kh * j.kw;
-    for (int e = b; e < n_el; e += 256) {
-        const int yy = reflect_pad(y0 + e / j.kw - j.sy, j.H), xx = reflect_pad(x0 + e % j.kw - j.sx, j.W);
-        atomicAdd(&h[lut[u[(int64_t)yy * j.W + xx]]], 1);
-    }
+    h[b] = j.maps[((int64_t)img * j.nty * j.ntx + tile) * 256 + b];      // the tile's histogram (k_clahe_hist); its map replaces it below
     __syncthreads();
     auto block_sum = [&](int v) -> int {                                  // every thread gets the sum
         v = (int)wave_sum_u32((uint32_t)v);
@@ -184,10 +208,10 @@ __global__ __launch_bounds__(256) void k_clahe_tiles(LinesJob j) {
 }
 
 // ---- stage 5: bilinear blend of the four neighbouring tile maps (_adapthist.py:176-210) ------------------------------------
-constexpr int kBlendRows = 64;                                       // a block blends a patch of kBlendRows rows by 256 columns
+constexpr int kBlendRows = 255;                                      // most rows a block blends (255 x 256 pixels fit its 16-bit counters)
 
-__global__ __launch_bounds__(256) void k_clahe_blend(LinesJob j) {
-    // level histogram of this block's pixels: 16-bit counters, two per word (a block sees kBlendRows * 256 = 16 384 pixels),
+__global__ __launch_bounds__(256) void k_clahe_blend(LinesJob j, int rows_per_block) {
+    // level histogram of this block's pixels: 16-bit counters, two per word (a block sees rows_per_block * 256 <= 65 280 pixels),
     // 32 KiB instead of 64 so that five blocks share a CU instead of two
     __shared__ uint32_t sh[8192];
     __shared__ double s_cy[kBlendRows];                                  // per row of the patch: weight of the lower tile row,
@@ -201,8 +225,8 @@ __global__ __launch_bounds__(256) void k_clahe_blend(LinesJob j) {
     uint16_t* __restrict__ lv = j.levels + (int64_t)img * npix;
     const int ncb = (j.W + 255) / 256;
     const int rb = blockIdx.x / ncb, cb = blockIdx.x - rb * ncb;
-    const int y0 = rb * kBlendRows, x = cb * 256 + threadIdx.x;
-    const int rows = min(kBlendRows, j.H - y0);
+    const int y0 = rb * rows_per_block, x = cb * 256 + threadIdx.x;
+    const int rows = min(rows_per_block, j.H - y0);
     // the divisions of _adapthist.py:176-210 are per row and per column, not per pixel: one thread per row of the patch
     // computes the row's, every thread its own column's
     if ((int)threadIdx.x < rows) {
@@ -367,7 +391,10 @@ __global__ __launch_bounds__(256) void k_ccl_init(LinesJob j) {
         for (int k = threadIdx.x; k < 2048; k += 256) dst[k] = src[k];
     }
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // Pixels of one class that sit side by side in a wave's 64 (one row) start out linked to the first of them: the long
+    // horizontal runs of a line never form a chain of single links, and k_ccl_merge only joins runs.
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;              // (a multiple of 64: a wave's pixels start at a multiple of 64)
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < npix; p0 += 4 * stride) {
         int l[4];
 #pragma unroll
@@ -375,13 +402,16 @@ __global__ __launch_bounds__(256) void k_ccl_init(LinesJob j) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int64_t p = p0 + k * stride;
-            if (p >= npix) break;
-            const uint16_t c = s_cls[l[k] & 16383];
-            cimg[p] = c;                                                 // the class image: what the labelling compares
-            parent[p] = c ? (int)p : -1;                                 // background takes no part
-            if (c) {
-                const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
-                bbox[p] = make_int4(y, x, y + 1, x + 1);                 // a root starts from its own pixel; the others add theirs
+            const bool valid = p < npix;                                 // (a valid lane's lower lanes are valid too)
+            const int c = valid ? (int)s_cls[l[k] & 16383] : 0;
+            const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
+            const int cleft = __shfl_up(c, 1);
+            const unsigned long long starts = __ballot(lane == 0 || x == 0 || c != cleft);
+            const int first = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane))));
+            if (valid) {
+                cimg[p] = (uint16_t)c;                                   // the class image: what the labelling compares
+                parent[p] = c ? (int)p - (lane - first) : -1;            // background takes no part
+                if (c) bbox[p] = make_int4(y, x, y + 1, x + 1);          // a root starts from its own pixel; the others add theirs
             }
         }
     }
@@ -392,22 +422,39 @@ __global__ __launch_bounds__(256) void k_ccl_merge(LinesJob j) {
     const int64_t npix = (int64_t)j.H * j.W;
     const uint16_t* __restrict__ cimg = j.cimg + (int64_t)img * npix;
     int32_t* parent = j.parent + (int64_t)img * npix;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
-        const uint16_t c = cimg[p];
-        if (!c) continue;
-        const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
-        const int64_t q = p - j.W;
-        const bool hasl = x > 0, hasu = y > 0, hasr = x + 1 < j.W;
-        const uint16_t cl = hasl ? cimg[p - 1] : (uint16_t)0, cu = hasu ? cimg[q] : (uint16_t)0;
-        const uint16_t cul = (hasu && hasl) ? cimg[q - 1] : (uint16_t)0, cur = (hasu && hasr) ? cimg[q + 1] : (uint16_t)0;
-        // the pixel joins its left and upper neighbours; a diagonal one only when no edge another pixel makes already
-        // links it (the upper pixel joins its own left neighbour, the upper right one joins the upper one, the left pixel
-        // joins the upper left one): the components are the same, with fewer walks to a root
-        if (cl == c) ccl_union(parent, (int)p, (int)p - 1);
-        if (cu == c) ccl_union(parent, (int)p, (int)q);
-        else {
-            if (cul == c && cl != c) ccl_union(parent, (int)p, (int)q - 1);
-            if (cur == c) ccl_union(parent, (int)p, (int)q + 1);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < npix; p0 += 4 * stride) {
+        // four pixels per step; all their loads are issued before the first walk to a root
+        int c[4], cl[4], cu[4], cul[4], cur[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int64_t p = p0 + k * stride; c[k] = p < npix ? cimg[p] : 0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t p = p0 + k * stride, q = p - j.W;
+            cl[k] = cu[k] = cul[k] = cur[k] = 0;
+            if (c[k]) {
+                const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
+                const bool hasl = x > 0, hasu = y > 0, hasr = x + 1 < j.W;
+                if (hasl) cl[k] = cimg[p - 1];
+                if (hasu) cu[k] = cimg[q];
+                if (hasu && hasl) cul[k] = cimg[q - 1];
+                if (hasu && hasr) cur[k] = cimg[q + 1];
+            }
+        }
+        // Only edges that no other link already implies are joined: the left neighbour across a wave boundary (inside a
+        // wave k_ccl_init linked the run), the upper neighbour where a run's overlap with the run above starts (the pixel
+        // to the left makes the same join otherwise), a diagonal one when neither the upper nor the left pixel carries
+        // it.  The components are the same, with far fewer walks to a root.
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!c[k]) continue;
+            const int p = (int)(p0 + k * stride), q = p - j.W;
+            if (cl[k] == c[k] && (p & 63) == 0) ccl_union(parent, p, p - 1);
+            if (cu[k] == c[k]) { if (!(cl[k] == c[k] && cul[k] == c[k])) ccl_union(parent, p, q); }
+            else {
+                if (cul[k] == c[k] && cl[k] != c[k]) ccl_union(parent, p, q - 1);
+                if (cur[k] == c[k]) ccl_union(parent, p, q + 1);
+            }
         }
     }
 }
@@ -514,8 +561,13 @@ hipError_t launch_lines(const LinesJob& j, LfaLineBox* out, int32_t* counts, int
     LFA_LAUNCH("k_lines_init", k_lines_init, dim3(4, j.n), blk, 0, s, j);
     LFA_LAUNCH("k_lines_local", k_lines_local, grid, blk, 0, s, j);
     LFA_LAUNCH("k_lines_binlut", k_lines_binlut, dim3(16, j.n), blk, 0, s, j);
+    LFA_LAUNCH("k_clahe_hist", k_clahe_hist, dim3(j.nty * j.ntx * kTileSlices, j.n), blk, 0, s, j);
     LFA_LAUNCH("k_clahe_tiles", k_clahe_tiles, dim3(j.nty * j.ntx, j.n), blk, 0, s, j);
-    LFA_LAUNCH("k_clahe_blend", k_clahe_blend, dim3(((j.W + 255) / 256) * ((j.H + kBlendRows - 1) / kBlendRows), j.n), blk, 0, s, j);
+    // rows per blend block: enough blocks to fill the chip (four per CU), then as many rows as possible -- a block ends with
+    // one global add per level it has seen, so fewer, taller patches spend less on that
+    const int ncb = (j.W + 255) / 256;
+    const int brows = (int)min((int64_t)kBlendRows, max((int64_t)16, (int64_t)j.H * ncb * j.n / 1024));
+    LFA_LAUNCH("k_clahe_blend", k_clahe_blend, dim3(ncb * ((j.H + brows - 1) / brows), j.n), blk, 0, s, j, brows);
     LFA_LAUNCH("k_lines_levels", k_lines_levels, dim3(j.n), dim3(1024), 0, s, j);
     LFA_LAUNCH("k_ccl_init", k_ccl_init, grid, blk, 0, s, j);
     LFA_LAUNCH("k_ccl_merge", k_ccl_merge, grid, blk, 0, s, j);
