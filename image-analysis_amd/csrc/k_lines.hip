@@ -382,7 +382,6 @@ __global__ __launch_bounds__(256) void k_ccl_init(LinesJob j) {
     const int img = blockIdx.y;
     const int64_t npix = (int64_t)j.H * j.W;
     int32_t* __restrict__ parent = j.parent + (int64_t)img * npix;
-    int4* __restrict__ bbox = (int4*)(j.bbox + (int64_t)img * npix * 4);
     const uint16_t* __restrict__ lv = j.levels + (int64_t)img * npix;
     uint16_t* __restrict__ cimg = j.cimg + (int64_t)img * npix;
     {
@@ -404,14 +403,13 @@ __global__ __launch_bounds__(256) void k_ccl_init(LinesJob j) {
             const int64_t p = p0 + k * stride;
             const bool valid = p < npix;                                 // (a valid lane's lower lanes are valid too)
             const int c = valid ? (int)s_cls[l[k] & 16383] : 0;
-            const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
+            const int x = (int)((uint32_t)p % (uint32_t)j.W);           // (p < 2^30)
             const int cleft = __shfl_up(c, 1);
             const unsigned long long starts = __ballot(lane == 0 || x == 0 || c != cleft);
             const int first = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane))));
             if (valid) {
                 cimg[p] = (uint16_t)c;                                   // the class image: what the labelling compares
                 parent[p] = c ? (int)p - (lane - first) : -1;            // background takes no part
-                if (c) bbox[p] = make_int4(y, x, y + 1, x + 1);          // a root starts from its own pixel; the others add theirs
             }
         }
     }
@@ -459,14 +457,21 @@ __global__ __launch_bounds__(256) void k_ccl_merge(LinesJob j) {
     }
 }
 
+// A component's box is kept as three extents from its root, which is its raster-first pixel and so lies in its top row:
+// rows down to the bottom edge, columns left to minc, columns right to maxc -- all "larger is wider" with 0 meaning "the
+// root's own pixel", so the table needs no initialisation per call: it is all zero between calls (lfa_detect_lines_batch
+// clears it when it allocates it, k_ccl_collect puts back the entries it reads).  A root some pixel points to is flagged in
+// the class image (0xffff, no class: classes are < 16 385), which the labelling no longer needs at this point.
 __global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
     const int img = blockIdx.y;
     const int64_t npix = (int64_t)j.H * j.W;
+    uint16_t* cimg = j.cimg + (int64_t)img * npix;
     int32_t* parent = j.parent + (int64_t)img * npix;
     int32_t* bbox = j.bbox + (int64_t)img * npix * 4;
     const int lane = threadIdx.x & 63;
+    uint32_t roots = 0;
     // A wave takes 64 consecutive pixels per step (wave-uniform loop).  Pixels of one component that sit side by side in a
-    // wave would all hit the same four words of their root: they are combined in the wave first (one leader per distinct
+    // wave would all hit the same words of their root: they are combined in the wave first (one leader per distinct
     // root, DPP reductions) -- per-pixel atomics on the few large components cost 1.4 of this kernel's 1.7 ms.
     for (int64_t pb = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); pb < npix; pb += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = pb + lane;
@@ -474,7 +479,8 @@ __global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
         bool need = false;
         if (p < npix) {
             const int up = parent[p];                                    // (-1: background, k_ccl_init)
-            if (up >= 0 && up != (int)p) {                               // (most components of a CLAHE'd frame are single pixels)
+            if (up == (int)p) ++roots;                                   // (most components of a CLAHE'd frame are single pixels)
+            else if (up >= 0) {
                 r = ccl_find(parent, up);
                 parent[p] = r;                                           // (others only ever point to smaller indices)
                 y = (int)((uint32_t)p / (uint32_t)j.W); x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);
@@ -486,38 +492,45 @@ __global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
             const int leader = __ffsll((unsigned long long)todo) - 1;
             const int lr = __shfl(r, leader);
             const bool mine = need && r == lr;
-            const int y0 = wave_min_i32(mine ? y : 0x7fffffff), x0 = wave_min_i32(mine ? x : 0x7fffffff);
+            const int x0 = wave_min_i32(mine ? x : 0x7fffffff);
             const int y1 = wave_max_i32(mine ? y + 1 : -1), x1 = wave_max_i32(mine ? x + 1 : -1);
             if (lane == leader) {
-                atomicMin(&bbox[4 * (int64_t)lr + 0], y0); atomicMin(&bbox[4 * (int64_t)lr + 1], x0);
-                atomicMax(&bbox[4 * (int64_t)lr + 2], y1); atomicMax(&bbox[4 * (int64_t)lr + 3], x1);
+                const int yr = (int)((uint32_t)lr / (uint32_t)j.W), xr = (int)((uint32_t)lr - (uint32_t)yr * (uint32_t)j.W);
+                int32_t* e = bbox + 4 * (int64_t)lr;
+                if (y1 - yr > 1) atomicMax(&e[0], y1 - yr);              // maxr - root row
+                if (xr - x0 > 0) atomicMax(&e[1], xr - x0);              // root column - minc
+                if (x1 - xr > 1) atomicMax(&e[2], x1 - xr);              // maxc - root column
+                cimg[lr] = (uint16_t)0xffff;
             }
             todo &= ~__ballot(mine);
         }
     }
+    roots = wave_sum_u32(roots);
+    if (lane == 0 && roots) atomicAdd(&j.info[img].n_labels, (int)roots);
 }
 
 // one candidate record per component that passes detection.py:191-199: root pixel, minr, maxr
 __global__ __launch_bounds__(256) void k_ccl_collect(LinesJob j) {
     const int img = blockIdx.y;
     const int64_t npix = (int64_t)j.H * j.W;
-    const int32_t* parent = j.parent + (int64_t)img * npix;
-    const int32_t* bbox = j.bbox + (int64_t)img * npix * 4;
+    const uint16_t* __restrict__ cimg = j.cimg + (int64_t)img * npix;
+    int4* bbox = (int4*)(j.bbox + (int64_t)img * npix * 4);
     const double min_area = (double)j.W * ((double)j.H * 0.0065), max_area = (double)j.W * ((double)j.H * 0.04);   // :159-160
     int32_t* cand = j.cand + (int64_t)img * j.cap * 3;
-    uint32_t roots = 0;
+    // (a root no pixel points to is a single pixel: one by one, never wider than tall, never a candidate)
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < npix; p0 += 4 * stride) {
-        int par[4];
+        int f[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const int64_t p = p0 + k * stride; par[k] = p < npix ? parent[p] : -1; }
+        for (int k = 0; k < 4; ++k) { const int64_t p = p0 + k * stride; f[k] = p < npix ? cimg[p] : 0; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            if (f[k] != 0xffff) continue;
             const int64_t p = p0 + k * stride;
-            if (par[k] != (int)p || p >= npix) continue;
-            ++roots;
-            const int4 b = ((const int4*)bbox)[p];
-            const int minr = b.x, minc = b.y, maxr = b.z, maxc = b.w;
+            const int4 e = bbox[p];
+            bbox[p] = make_int4(0, 0, 0, 0);                             // the table is all zero again when the call ends
+            const int yr = (int)((uint32_t)p / (uint32_t)j.W), xr = (int)((uint32_t)p - (uint32_t)yr * (uint32_t)j.W);
+            const int minr = yr, maxr = yr + max(e.x, 1), minc = xr - e.y, maxc = xr + max(e.z, 1);
             const int64_t area = (int64_t)(maxc - minc) * (maxr - minr);
             // wider than tall and min_area < area < max_area: the box is widened to the whole image width and kept (:193-200)
             if ((maxc - minc) > (maxr - minr) && (double)area > min_area && (double)area < max_area) {
@@ -526,8 +539,6 @@ __global__ __launch_bounds__(256) void k_ccl_collect(LinesJob j) {
             }
         }
     }
-    roots = wave_sum_u32(roots);
-    if ((threadIdx.x & 63) == 0 && roots) atomicAdd(&j.info[img].n_labels, (int)roots);
 }
 
 // regionprops order = label order = raster order of the first pixel = ascending root index

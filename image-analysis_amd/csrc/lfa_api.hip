@@ -162,6 +162,7 @@ struct LfaContext {
     int u16_thr_mean = 0, u16_thr_spread = 0;   // mean and (largest - smallest) threshold of that call
     int win_hint = 0;                      // longest analysis window of the last completed call (rows), 0 = unknown
     // detect_lines workspace (lfa_detect_lines_batch), allocated by the first call that needs it
+    bool ln_bbox_dirty = false;
     Buf ln_g, ln_u, ln_binlut, ln_maps, ln_levels, ln_lhist, ln_lval, ln_cls, ln_cimg, ln_parent, ln_bbox, ln_cand, ln_info;
     lfa::LinesJob lines_last{};
     bool have_lines = false;
@@ -754,9 +755,14 @@ int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, in
     if ((rc = ensure(h->ln_g, N * npix * 8)) || (rc = ensure(h->ln_u, N * npix * 2)) || (rc = ensure(h->ln_binlut, N * 65536)) ||
         (rc = ensure(h->ln_maps, N * (size_t)j.nty * j.ntx * 256 * 4)) || (rc = ensure(h->ln_levels, N * npix * 2)) ||
         (rc = ensure(h->ln_lhist, N * 16384 * 4)) || (rc = ensure(h->ln_lval, N * 16384 * 8)) || (rc = ensure(h->ln_cls, N * 16384 * 2)) || (rc = ensure(h->ln_cimg, N * npix * 2)) ||
-        (rc = ensure(h->ln_parent, N * npix * 4)) || (rc = ensure(h->ln_bbox, N * npix * 16)) ||
+        (rc = ensure(h->ln_parent, N * npix * 4)) ||
         (rc = ensure(h->ln_cand, N * (size_t)j.cap * 12)) || (rc = ensure(h->ln_info, N * sizeof(LfaLinesInfo))))
         return rc;
+    // the box extents table is all zero between calls (k_ccl_boxes / k_ccl_collect, k_lines.hip): cleared when it is
+    // allocated, and again after a call whose launches did not all go out
+    const void* bbox_was = h->ln_bbox.p;
+    if ((rc = ensure(h->ln_bbox, N * npix * 16))) return rc;
+    const bool clear_bbox = h->ln_bbox.p != bbox_was || h->ln_bbox_dirty;
     j.g = (const double*)h->ln_g.p; j.u = (uint16_t*)h->ln_u.p; j.binlut = (uint8_t*)h->ln_binlut.p; j.maps = (int32_t*)h->ln_maps.p;
     j.levels = (uint16_t*)h->ln_levels.p; j.lhist = (uint32_t*)h->ln_lhist.p; j.lval = (double*)h->ln_lval.p; j.cls = (uint16_t*)h->ln_cls.p; j.cimg = (uint16_t*)h->ln_cimg.p;
     j.parent = (int32_t*)h->ln_parent.p; j.bbox = (int32_t*)h->ln_bbox.p; j.cand = (int32_t*)h->ln_cand.p; j.info = (LfaLinesInfo*)h->ln_info.p;
@@ -766,9 +772,12 @@ int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, in
     gj.n = n; gj.H = H; gj.W = W; gj.C = 1; gj.dtype = dtype;
     gj.aligned16 = (((uintptr_t)images & 15) == 0 && (gj.img_bytes & 15) == 0) ? 1 : 0;
     if (h->have_done && s != h->last_stream) LFA_HIP(hipStreamWaitEvent(s, h->done_event, 0));
+    if (clear_bbox) { LFA_HIP(hipMemsetAsync(h->ln_bbox.p, 0, h->ln_bbox.bytes, s)); h->ln_bbox_dirty = false; }
     TimerScope ts(h);
     LFA_HIP(lfa::launch_gaussian_w(gj, w9, 4, h->ln_g.p, 0, s));                 // detection.py:166
+    h->ln_bbox_dirty = true;
     LFA_HIP(lfa::launch_lines(j, out_boxes, out_counts, max_boxes, s));
+    h->ln_bbox_dirty = false;
     if (out_info) LFA_HIP(hipMemcpyAsync(out_info, j.info, N * sizeof(LfaLinesInfo), hipMemcpyDeviceToDevice, s));
     LFA_HIP(hipEventRecord(h->done_event, s));
     h->last_stream = s; h->have_done = true;
