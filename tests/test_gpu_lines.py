@@ -120,6 +120,37 @@ def test_batch_of_different_images_and_box_overflow(capi, eng):
     assert got == want
 
 
+def test_box_table_is_clean_between_calls_of_different_shapes(capi, eng):
+    """the box extents table is never initialised per call (k_ccl_collect puts back what it reads): a large frame, a small
+    one and a batch whose images sit at other offsets in the same table, twice over, each against the oracle"""
+    from oracle import lines_oracle as L
+    from image_analysis_amd.synth import synth_lines
+    big, small = synth_lines(768, 1024, 31, np.uint8), synth_lines(200, 264, 32, np.uint8)
+    batch = np.stack([synth_lines(384, 512, 33 + k, np.uint8) for k in range(3)])
+    want_batch = [L.detect_lines(im) for im in batch]
+    assert all(len(w) > 0 for w in want_batch) and len(L.detect_lines(big)) > 0
+    for _ in range(2):
+        _against_oracle(capi, eng, big)
+        _against_oracle(capi, eng, small)
+        boxes, info = eng.detect_lines(batch)
+        assert [[[int(b["minr"]), int(b["maxr"]), int(b["minc"]), int(b["maxc"])] for b in bx] for bx in boxes] == want_batch
+        boxes, info = eng.detect_lines(batch, max_boxes=1)          # the overflow path leaves the table clean too
+        assert [[[int(b["minr"]), int(b["maxr"]), int(b["minc"]), int(b["maxc"])] for b in bx] for bx in boxes] == want_batch
+
+
+def test_boxes_of_components_that_spread_left_and_below_their_first_pixel(capi, eng):
+    """a component's box is kept as extents from its raster-first pixel: bright shapes whose first pixel is neither their
+    leftmost nor their only top-row pixel (a wide bar hanging from a thin stem on its right, a staircase to the left)"""
+    H, W = 256, 320
+    rng = np.random.default_rng(5)
+    im = rng.integers(0, 40, size=(H, W)).astype(np.uint8)
+    im[60:64, 290:294] = 255; im[64:76, 10:294] = 255                  # stem at the right end, bar to the left below it
+    for k in range(12):
+        im[150 + k, 300 - 24 * k - 30:300 - 24 * k] = 255               # staircase: every step further left
+    d = _against_oracle(capi, eng, im)
+    assert d["labels"].max() > 2
+
+
 def test_drop_in_detect_lines(capi):
     import image_analysis_amd.detection as detection
     from oracle import lines_oracle as L
