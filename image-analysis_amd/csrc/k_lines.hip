@@ -21,6 +21,7 @@
 // -ffp-contract=off (the build's flag): every float operation below is the single IEEE operation numpy performs.
 #include "lfa_internal.h"
 #include "lfa_device.h"
+#include <type_traits>
 
 namespace lfa {
 
@@ -216,6 +217,7 @@ __global__ __launch_bounds__(256) void k_clahe_blend(LinesJob j, int rows_per_bl
     __shared__ uint32_t sh[8192];
     __shared__ double s_cy[kBlendRows];                                  // per row of the patch: weight of the lower tile row,
     __shared__ int s_ty[kBlendRows][2];                                  // offsets of the two tile rows' maps
+    __shared__ uint16_t s_maps[9 * 256];
     for (int k = threadIdx.x; k < 8192; k += 256) sh[k] = 0u;
     const int img = blockIdx.y;
     const int64_t npix = (int64_t)j.H * j.W;
@@ -227,20 +229,37 @@ __global__ __launch_bounds__(256) void k_clahe_blend(LinesJob j, int rows_per_bl
     const int rb = blockIdx.x / ncb, cb = blockIdx.x - rb * ncb;
     const int y0 = rb * rows_per_block, x = cb * 256 + threadIdx.x;
     const int rows = min(rows_per_block, j.H - y0);
+    // The tile maps this patch blends between: tile rows ty_a..ty_b, tile columns tx_a..tx_b.  When they are at most nine
+    // (always, for patches no larger than a tile) the block copies them into LDS as 16-bit values (a map entry is at most
+    // 16 383) and the four lookups per pixel never leave the CU; otherwise they stay gathers from global memory.
+    const int x_last = min(j.W, cb * 256 + 256) - 1;
+    const int ty_a = min(max((y0 + j.sy) / j.kh - 1, 0), j.nty - 1), ty_b = min(max((y0 + rows - 1 + j.sy) / j.kh, 0), j.nty - 1);
+    const int tx_a = min(max((cb * 256 + j.sx) / j.kw - 1, 0), j.ntx - 1), tx_b = min(max((x_last + j.sx) / j.kw, 0), j.ntx - 1);
+    const int nyt = ty_b - ty_a + 1, nxt = tx_b - tx_a + 1;
+    const bool staged = nyt * nxt <= 9;
+    if (staged) {
+        for (int k = threadIdx.x; k < nyt * nxt * 256; k += 256) {
+            const int t = k >> 8, tyy = ty_a + t / nxt, txx = tx_a + t % nxt;
+            s_maps[k] = (uint16_t)maps[((int64_t)tyy * j.ntx + txx) * 256 + (k & 255)];
+        }
+    }
     // the divisions of _adapthist.py:176-210 are per row and per column, not per pixel: one thread per row of the patch
     // computes the row's, every thread its own column's
     if ((int)threadIdx.x < rows) {
         const int py = y0 + threadIdx.x + j.sy, by = py / j.kh;
+        const int t0 = min(max(by - 1, 0), j.nty - 1), t1 = min(max(by, 0), j.nty - 1);
         s_cy[threadIdx.x] = (double)(py % j.kh) / (double)j.kh;
-        s_ty[threadIdx.x][0] = min(max(by - 1, 0), j.nty - 1) * j.ntx * 256;
-        s_ty[threadIdx.x][1] = min(max(by, 0), j.nty - 1) * j.ntx * 256;
+        s_ty[threadIdx.x][0] = staged ? (t0 - ty_a) * nxt * 256 : t0 * j.ntx * 256;
+        s_ty[threadIdx.x][1] = staged ? (t1 - ty_a) * nxt * 256 : t1 * j.ntx * 256;
     }
     __syncthreads();
     int lo = 65535, hi = 0;
-    if (x < j.W) {
+    auto blend = [&](auto staged_c) {
+        constexpr bool kStaged = decltype(staged_c)::value;
         const int px = x + j.sx, bx = px / j.kw;
         const double cx1 = (double)(px % j.kw) / (double)j.kw, cx0 = 1.0 - cx1;
-        const int tx0 = min(max(bx - 1, 0), j.ntx - 1) * 256, tx1 = min(max(bx, 0), j.ntx - 1) * 256;
+        const int c0 = min(max(bx - 1, 0), j.ntx - 1), c1 = min(max(bx, 0), j.ntx - 1);
+        const int tx0 = (kStaged ? c0 - tx_a : c0) * 256, tx1 = (kStaged ? c1 - tx_a : c1) * 256;
         for (int r0 = 0; r0 < rows; r0 += 4) {                           // four rows per step: their loads are issued together
             int bin[4], m[4][4];
 #pragma unroll
@@ -250,8 +269,13 @@ __global__ __launch_bounds__(256) void k_clahe_blend(LinesJob j, int rows_per_bl
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int r = min(r0 + k, rows - 1), t0 = s_ty[r][0], t1 = s_ty[r][1];
-                m[k][0] = maps[t0 + tx0 + bin[k]]; m[k][1] = maps[t0 + tx1 + bin[k]];
-                m[k][2] = maps[t1 + tx0 + bin[k]]; m[k][3] = maps[t1 + tx1 + bin[k]];
+                if (kStaged) {
+                    m[k][0] = s_maps[t0 + tx0 + bin[k]]; m[k][1] = s_maps[t0 + tx1 + bin[k]];
+                    m[k][2] = s_maps[t1 + tx0 + bin[k]]; m[k][3] = s_maps[t1 + tx1 + bin[k]];
+                } else {
+                    m[k][0] = maps[t0 + tx0 + bin[k]]; m[k][1] = maps[t0 + tx1 + bin[k]];
+                    m[k][2] = maps[t1 + tx0 + bin[k]]; m[k][3] = maps[t1 + tx1 + bin[k]];
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -268,6 +292,9 @@ __global__ __launch_bounds__(256) void k_clahe_blend(LinesJob j, int rows_per_bl
                 lo = min(lo, q); hi = max(hi, q);
             }
         }
+    };
+    if (x < j.W) {
+        if (staged) blend(std::true_type{}); else blend(std::false_type{});
     }
     lo = wave_min_i32(lo); hi = wave_max_i32(hi);
     if ((threadIdx.x & 63) == 0 && hi >= lo) { atomicMin(&j.info[img].cmin, lo); atomicMax(&j.info[img].cmax, hi); }
