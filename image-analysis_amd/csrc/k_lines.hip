@@ -30,7 +30,7 @@ __device__ __forceinline__ int reflect_half(int i, int n) {         // scipy 're
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
-constexpr int kLocalRows = 4;                                        // rows one wave filters per step (kLocalRows + 2 loads in flight per lane)
+constexpr int kLocalRows = 8;                                        // rows one wave filters per step (kLocalRows + 2 loads in flight per lane)
 
 __global__ __launch_bounds__(256) void k_lines_local(LinesJob j) {
     const int img = blockIdx.y;
@@ -500,12 +500,17 @@ __global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
     // A wave takes 64 consecutive pixels per step (wave-uniform loop).  Pixels of one component that sit side by side in a
     // wave would all hit the same words of their root: they are combined in the wave first (one leader per distinct
     // root, DPP reductions) -- per-pixel atomics on the few large components cost 1.4 of this kernel's 1.7 ms.
-    for (int64_t pb = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); pb < npix; pb += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = pb + lane;
-        int r = -1, y = 0, x = 0;
-        bool need = false;
-        if (p < npix) {
-            const int up = parent[p];                                    // (-1: background, k_ccl_init)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t pb0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); pb0 < npix; pb0 += 4 * stride) {
+        int ups[4];                                                      // four segments per step: their loads go out together
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int64_t p = pb0 + k * stride + lane; ups[k] = p < npix ? parent[p] : -1; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t p = pb0 + k * stride + lane;
+            const int up = ups[k];                                       // (-1: background, k_ccl_init; this lane's own entry: only it writes it)
+            int r = -1, y = 0, x = 0;
+            bool need = false;
             if (up == (int)p) ++roots;                                   // (most components of a CLAHE'd frame are single pixels)
             else if (up >= 0) {
                 r = ccl_find(parent, up);
@@ -513,23 +518,23 @@ __global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
                 y = (int)((uint32_t)p / (uint32_t)j.W); x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);
                 need = true;
             }
-        }
-        unsigned long long todo = __ballot(need);
-        while (todo) {
-            const int leader = __ffsll((unsigned long long)todo) - 1;
-            const int lr = __shfl(r, leader);
-            const bool mine = need && r == lr;
-            const int x0 = wave_min_i32(mine ? x : 0x7fffffff);
-            const int y1 = wave_max_i32(mine ? y + 1 : -1), x1 = wave_max_i32(mine ? x + 1 : -1);
-            if (lane == leader) {
-                const int yr = (int)((uint32_t)lr / (uint32_t)j.W), xr = (int)((uint32_t)lr - (uint32_t)yr * (uint32_t)j.W);
-                int32_t* e = bbox + 4 * (int64_t)lr;
-                if (y1 - yr > 1) atomicMax(&e[0], y1 - yr);              // maxr - root row
-                if (xr - x0 > 0) atomicMax(&e[1], xr - x0);              // root column - minc
-                if (x1 - xr > 1) atomicMax(&e[2], x1 - xr);              // maxc - root column
-                cimg[lr] = (uint16_t)0xffff;
+            unsigned long long todo = __ballot(need);
+            while (todo) {
+                const int leader = __ffsll((unsigned long long)todo) - 1;
+                const int lr = __shfl(r, leader);
+                const bool mine = need && r == lr;
+                const int x0 = wave_min_i32(mine ? x : 0x7fffffff);
+                const int y1 = wave_max_i32(mine ? y + 1 : -1), x1 = wave_max_i32(mine ? x + 1 : -1);
+                if (lane == leader) {
+                    const int yr = (int)((uint32_t)lr / (uint32_t)j.W), xr = (int)((uint32_t)lr - (uint32_t)yr * (uint32_t)j.W);
+                    int32_t* e = bbox + 4 * (int64_t)lr;
+                    if (y1 - yr > 1) atomicMax(&e[0], y1 - yr);          // maxr - root row
+                    if (xr - x0 > 0) atomicMax(&e[1], xr - x0);          // root column - minc
+                    if (x1 - xr > 1) atomicMax(&e[2], x1 - xr);          // maxc - root column
+                    cimg[lr] = (uint16_t)0xffff;
+                }
+                todo &= ~__ballot(mine);
             }
-            todo &= ~__ballot(mine);
         }
     }
     roots = wave_sum_u32(roots);
