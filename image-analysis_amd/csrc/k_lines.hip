@@ -30,56 +30,115 @@ __device__ __forceinline__ int reflect_half(int i, int n) {         // scipy 're
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 
-constexpr int kLocalRows = 8;                                        // rows one wave filters per step (kLocalRows + 2 loads in flight per lane)
+// One kernel for detection.py:166-172: skimage.filters.gaussian(sigma 1) -- img_as_float, then scipy's correlate1d along axis 0
+// and along axis 1 with 'nearest' borders, exactly as k_gaussian.hip restates it (tmp = x[0]*w[R]; tmp += (x[-k] + x[+k]) *
+// w[R-k] for k = R..1) -- then threshold_local's 3-tap Gaussian ('reflect' borders) of that result, the product with
+// (t > 0), sqrt and img_as_uint.  The float64 Gaussian image never leaves the CU (8 bytes per pixel written and read back
+// otherwise); it is stored only when the parity tests ask for it (j.g, debug flag 64).
+// A block stages kFIW columns x (kFTH + 2 + 2R) rows: vertical pass into LDS (one staged column per thread, all rows
+// requested before the first is used, sliding register window), horizontal pass out of LDS and back into it (the
+// Gaussian on kFTH + 2 rows x kFIW - 2R columns), then the local filter on the inner kFTH x (kFIW - 2R - 2) pixels.
+constexpr int kFR = 4, kFTH = 8, kFIW = 256, kFOC = kFIW - 2 * (kFR + 1);
 
-__global__ __launch_bounds__(256) void k_lines_local(LinesJob j) {
-    const int img = blockIdx.y;
+template <typename PIX>
+__global__ __launch_bounds__(kFIW) void k_lines_front(LinesJob j) {
+    __shared__ double v[(kFTH + 2) * kFIW];
+    __shared__ int s_red[2 * (kFIW / 64)];
+    const int img = blockIdx.z, t = threadIdx.x;
+    const PIX* __restrict__ base = (const PIX*)(j.images + (int64_t)img * j.img_bytes);
+    const int x0 = blockIdx.x * kFOC, r0 = blockIdx.y * kFTH;
+    const double scale = (sizeof(PIX) == 1) ? (1.0 / 255.0) : (1.0 / 65535.0);
+    double w[kFR + 1];
+#pragma unroll
+    for (int k = 0; k <= kFR; ++k) w[k] = j.wg[k];
+    {   // axis 0: staged column t is image column x0 - (R + 1) + t ('nearest'), rows r0 - 1 - R .. r0 + kFTH + R
+        const PIX* col = base + min(max(x0 - (kFR + 1) + t, 0), j.W - 1);
+        PIX raw[kFTH + 2 + 2 * kFR];
+#pragma unroll
+        for (int k = 0; k < kFTH + 2 + 2 * kFR; ++k) raw[k] = col[(int64_t)min(max(r0 - 1 - kFR + k, 0), j.H - 1) * j.W];
+        double win[2 * kFR + 1];
+#pragma unroll
+        for (int k = 0; k < 2 * kFR; ++k) win[k + 1] = (double)raw[k] * scale;
+#pragma unroll
+        for (int rr = 0; rr < kFTH + 2; ++rr) {
+#pragma unroll
+            for (int k = 0; k < 2 * kFR; ++k) win[k] = win[k + 1];
+            win[2 * kFR] = (double)raw[rr + 2 * kFR] * scale;
+            double tmp = win[kFR] * w[kFR];
+#pragma unroll
+            for (int q = kFR; q >= 1; --q) tmp = tmp + (win[kFR - q] + win[kFR + q]) * w[kFR - q];
+            v[rr * kFIW + t] = tmp;
+        }
+    }
+    __syncthreads();
+    {   // axis 1, in place: every thread holds its column's results until all have read their taps
+        double h[kFTH + 2];
+        const bool has = t >= kFR && t < kFIW - kFR;
+        if (has) {
+#pragma unroll
+            for (int rr = 0; rr < kFTH + 2; ++rr) {
+                const double* row = v + rr * kFIW + t;
+                double tmp = row[0] * w[kFR];
+#pragma unroll
+                for (int q = kFR; q >= 1; --q) tmp = tmp + (row[-q] + row[q]) * w[kFR - q];
+                h[rr] = tmp;
+            }
+        }
+        __syncthreads();
+        if (has) {
+#pragma unroll
+            for (int rr = 0; rr < kFTH + 2; ++rr) v[rr * kFIW + t] = h[rr];
+        }
+    }
+    __syncthreads();
+    // the local filter: LDS row rr is image row r0 - 1 + rr, LDS column tt image column x0 - (R + 1) + tt; 'reflect' with an
+    // overshoot of one is the clamp of the row / column index
     const int64_t npix = (int64_t)j.H * j.W;
-    const double* __restrict__ g = j.g + (int64_t)img * npix;
     uint16_t* __restrict__ u = j.u + (int64_t)img * npix;
-    int lo = 65535, hi = 0;
-    int over = 0;
-    const int lane = threadIdx.x & 63;
-    // A wave takes a patch of kLocalRows rows by 64 columns per step and writes the 62 columns in its middle: every lane
-    // filters its own column along axis 0 (a sliding window over kLocalRows + 2 loads, all issued before the first use) and
-    // takes the two neighbouring column results from the lanes beside it, so lanes 0 and 63 only supply their column.  No
-    // lane ever computes a neighbour's column itself (a branch that one lane of every wave would take costs the whole wave
-    // its latency), and 'reflect' at the frame's edges is the clamp of the column / row index (overshoot 1).
-    const int ncg = (j.W + 61) / 62, nrg = (j.H + kLocalRows - 1) / kLocalRows;
-    const int64_t tasks = (int64_t)ncg * nrg;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t t = wave; t < tasks; t += nwaves) {
-        const int rg = (int)(t / ncg), cg = (int)(t - (int64_t)rg * ncg);
-        const int x = cg * 62 + lane - 1, xc = reflect_half(x, j.W);
-        const int y0 = rg * kLocalRows;
-        double v[kLocalRows + 2];
+    const int x = x0 - (kFR + 1) + t;
+    int lo = 65535, hi = 0, over = 0;
+    if (t >= kFR + 1 && t < kFIW - kFR - 1 && x < j.W) {
+        const int tm = max(x - 1, 0) - (x0 - (kFR + 1)), tp = min(x + 1, j.W - 1) - (x0 - (kFR + 1));
 #pragma unroll
-        for (int k = 0; k < kLocalRows + 2; ++k) v[k] = g[(int64_t)reflect_half(y0 - 1 + k, j.H) * j.W + xc];
-        const bool writes = lane >= 1 && lane <= 62 && x < j.W;
-#pragma unroll
-        for (int r = 0; r < kLocalRows; ++r) {
-            if (y0 + r >= j.H) break;                                 // (wave-uniform)
-            double c0 = v[r + 1] * j.w0;                              // axis 0 first (scipy.ndimage.gaussian_filter)
-            c0 += (v[r] + v[r + 2]) * j.w1;
-            const double cm = __shfl_up(c0, 1), cp = __shfl_down(c0, 1);
+        for (int rr = 0; rr < kFTH; ++rr) {
+            const int y = r0 + rr;
+            if (y >= j.H) break;
+            const double* rc = v + (rr + 1) * kFIW;
+            const double* rm = v + (max(y - 1, 0) - (r0 - 1)) * kFIW;
+            const double* rp = v + (min(y + 1, j.H - 1) - (r0 - 1)) * kFIW;
+            auto col = [&](int tt) -> double {                        // axis 0 first (scipy.ndimage.gaussian_filter)
+                double c = rc[tt] * j.w0;
+                c += (rm[tt] + rp[tt]) * j.w1;
+                return c;
+            };
+            const double gv = rc[t];
+            const double c0 = col(t), cm = col(tm), cp = col(tp);
             double tl = c0 * j.w0;
             tl += (cm + cp) * j.w1;
-            const double gv = v[r + 1];
             const double xg = (tl - 0.0 > 0.0) ? gv * 1.0 : gv * 0.0; // image_copy * (thresholded_image > 0), detection.py:170
             const double sq = sqrt(xg / 1.0) * 1.0 * 1.0;             // ((image / scale) ** gamma) * scale * gain
             double q = rint(sq * 65535.0);
             q = q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q);
             const int qi = (int)q;
-            if (writes) {
-                if (sq > 1.0 || sq < -1.0) over = 1;                  // img_as_uint refuses such an image
-                u[(int64_t)(y0 + r) * j.W + x] = (uint16_t)qi;
-                lo = min(lo, qi); hi = max(hi, qi);
-            }
+            if (sq > 1.0 || sq < -1.0) over = 1;                      // img_as_uint refuses such an image
+            u[(int64_t)y * j.W + x] = (uint16_t)qi;
+            lo = min(lo, qi); hi = max(hi, qi);
+            if (j.g) j.g[(int64_t)img * npix + (int64_t)y * j.W + x] = gv;
         }
     }
+    // the frame's extremes: one pair of atomics per block, and none once the frame's running extremes already cover the block's
     lo = wave_min_i32(lo); hi = wave_max_i32(hi);
-    if ((threadIdx.x & 63) == 0 && hi >= lo) { atomicMin(&j.info[img].umin, lo); atomicMax(&j.info[img].umax, hi); }
+    if ((t & 63) == 0) { s_red[t >> 6] = lo; s_red[kFIW / 64 + (t >> 6)] = hi; }
     if (over) atomicOr(&j.info[img].status, 2);
+    __syncthreads();
+    if (t == 0) {
+#pragma unroll
+        for (int k = 1; k < kFIW / 64; ++k) { lo = min(lo, s_red[k]); hi = max(hi, s_red[kFIW / 64 + k]); }
+        if (hi >= lo) {
+            if (lo < __atomic_load_n(&j.info[img].umin, __ATOMIC_RELAXED)) atomicMin(&j.info[img].umin, lo);
+            if (hi > __atomic_load_n(&j.info[img].umax, __ATOMIC_RELAXED)) atomicMax(&j.info[img].umax, hi);
+        }
+    }
 }
 
 __global__ void k_lines_init(LinesJob j) {
@@ -602,7 +661,11 @@ hipError_t launch_lines(const LinesJob& j, LfaLineBox* out, int32_t* counts, int
     if (bpi < 1) bpi = 1;
     const dim3 grid(bpi, j.n), blk(256);
     LFA_LAUNCH("k_lines_init", k_lines_init, dim3(4, j.n), blk, 0, s, j);
-    LFA_LAUNCH("k_lines_local", k_lines_local, grid, blk, 0, s, j);
+    {
+        const dim3 fgrid((j.W + kFOC - 1) / kFOC, (j.H + kFTH - 1) / kFTH, j.n);
+        if (j.dtype == LFA_U16) LFA_LAUNCH("k_lines_front", k_lines_front<uint16_t>, fgrid, dim3(kFIW), 0, s, j);
+        else LFA_LAUNCH("k_lines_front", k_lines_front<uint8_t>, fgrid, dim3(kFIW), 0, s, j);
+    }
     LFA_LAUNCH("k_lines_binlut", k_lines_binlut, dim3(16, j.n), blk, 0, s, j);
     LFA_LAUNCH("k_clahe_hist", k_clahe_hist, dim3(j.nty * j.ntx * kTileSlices, j.n), blk, 0, s, j);
     LFA_LAUNCH("k_clahe_tiles", k_clahe_tiles, dim3(j.nty * j.ntx, j.n), blk, 0, s, j);

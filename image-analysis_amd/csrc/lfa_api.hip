@@ -370,6 +370,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (rc) return rc;
     if (H > 65535 || W > 65535) return fail(LFA_ERR_ARG, "image sides above 65535 are not supported");
     if ((long long)H * W > (1ll << 30)) return fail(LFA_ERR_UNSUPPORTED, "images above 2^30 pixels are not supported");
+    if (n > 65535 || (H + 7) / 8 > 65535) return fail(LFA_ERR_UNSUPPORTED, "more than 65535 frames per call, or frames taller than 524280 rows, are not supported");
     if (L < 1) return fail(LFA_ERR_ARG, "line_length must be >= 1");
     if (min_maxr < 0 || min_maxc < 0) return fail(LFA_ERR_ARG, "min_maxr/min_maxc must be >= 0");
     if (!out_strips || !out_counts) return fail(LFA_ERR_ARG, "null output pointer");
@@ -723,6 +724,7 @@ int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, in
     if (!out_boxes || !out_counts) return fail(LFA_ERR_ARG, "null output pointer");
     if (max_boxes < 1 || max_boxes > 65536) return fail(LFA_ERR_ARG, "max_boxes must be in [1,65536]");
     if ((long long)H * W > (1ll << 30)) return fail(LFA_ERR_UNSUPPORTED, "images above 2^30 pixels are not supported");
+    if (n > 65535 || (H + 7) / 8 > 65535) return fail(LFA_ERR_UNSUPPORTED, "more than 65535 frames per call, or frames taller than 524280 rows, are not supported");
     // scipy.ndimage._filters._gaussian_kernel1d: exp(-0.5 / sigma^2 * x^2), normalised by the plain sum
     auto taps = [](double sigma, int radius, double* w) {
         const double sigma2 = sigma * sigma;
@@ -752,7 +754,8 @@ int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, in
     j.cap = max_boxes;
     j.w0 = w3[1]; j.w1 = w3[0];
     const size_t N = (size_t)n, npix = (size_t)H * W;
-    if ((rc = ensure(h->ln_g, N * npix * 8)) || (rc = ensure(h->ln_u, N * npix * 2)) || (rc = ensure(h->ln_binlut, N * 65536)) ||
+    const bool keep_gauss = (h->debug_flags & 64) != 0;                           // lfa_lines_debug_fetch(LFA_LDBG_GAUSS) needs it
+    if ((keep_gauss && (rc = ensure(h->ln_g, N * npix * 8))) || (rc = ensure(h->ln_u, N * npix * 2)) || (rc = ensure(h->ln_binlut, N * 65536)) ||
         (rc = ensure(h->ln_maps, N * (size_t)j.nty * j.ntx * 256 * 4)) || (rc = ensure(h->ln_levels, N * npix * 2)) ||
         (rc = ensure(h->ln_lhist, N * 16384 * 4)) || (rc = ensure(h->ln_lval, N * 16384 * 8)) || (rc = ensure(h->ln_cls, N * 16384 * 2)) || (rc = ensure(h->ln_cimg, N * npix * 2)) ||
         (rc = ensure(h->ln_parent, N * npix * 4)) ||
@@ -763,18 +766,14 @@ int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, in
     const void* bbox_was = h->ln_bbox.p;
     if ((rc = ensure(h->ln_bbox, N * npix * 16))) return rc;
     const bool clear_bbox = h->ln_bbox.p != bbox_was || h->ln_bbox_dirty;
-    j.g = (const double*)h->ln_g.p; j.u = (uint16_t*)h->ln_u.p; j.binlut = (uint8_t*)h->ln_binlut.p; j.maps = (int32_t*)h->ln_maps.p;
+    j.g = keep_gauss ? (double*)h->ln_g.p : nullptr; j.u = (uint16_t*)h->ln_u.p; j.binlut = (uint8_t*)h->ln_binlut.p; j.maps = (int32_t*)h->ln_maps.p;
     j.levels = (uint16_t*)h->ln_levels.p; j.lhist = (uint32_t*)h->ln_lhist.p; j.lval = (double*)h->ln_lval.p; j.cls = (uint16_t*)h->ln_cls.p; j.cimg = (uint16_t*)h->ln_cimg.p;
     j.parent = (int32_t*)h->ln_parent.p; j.bbox = (int32_t*)h->ln_bbox.p; j.cand = (int32_t*)h->ln_cand.p; j.info = (LfaLinesInfo*)h->ln_info.p;
-    lfa::Job gj{};
-    gj.images = (const uint8_t*)images;
-    gj.img_bytes = (int64_t)H * W * (dtype == LFA_U16 ? 2 : 1);
-    gj.n = n; gj.H = H; gj.W = W; gj.C = 1; gj.dtype = dtype;
-    gj.aligned16 = (((uintptr_t)images & 15) == 0 && (gj.img_bytes & 15) == 0) ? 1 : 0;
+    j.images = (const uint8_t*)images; j.img_bytes = (int64_t)H * W * (dtype == LFA_U16 ? 2 : 1); j.dtype = dtype;
+    for (int k = 0; k < 5; ++k) j.wg[k] = w9[k];
     if (h->have_done && s != h->last_stream) LFA_HIP(hipStreamWaitEvent(s, h->done_event, 0));
     if (clear_bbox) { LFA_HIP(hipMemsetAsync(h->ln_bbox.p, 0, h->ln_bbox.bytes, s)); h->ln_bbox_dirty = false; }
     TimerScope ts(h);
-    LFA_HIP(lfa::launch_gaussian_w(gj, w9, 4, h->ln_g.p, 0, s));                 // detection.py:166
     h->ln_bbox_dirty = true;
     LFA_HIP(lfa::launch_lines(j, out_boxes, out_counts, max_boxes, s));
     h->ln_bbox_dirty = false;
@@ -794,7 +793,9 @@ int lfa_lines_debug_fetch(LfaHandle h, int image_index, int what, void* out, int
     const void* src = nullptr;
     int64_t bytes = 0;
     switch (what) {
-        case LFA_LDBG_GAUSS:  src = j.g + image_index * npix; bytes = npix * 8; break;
+        case LFA_LDBG_GAUSS:
+            if (!j.g) return fail(LFA_ERR_ARG, "the Gaussian image is kept only when debug flag 64 was set before the call (lfa_set_debug_flags)");
+            src = j.g + image_index * npix; bytes = npix * 8; break;
         case LFA_LDBG_U16:    src = j.u + image_index * npix; bytes = npix * 2; break;
         case LFA_LDBG_LEVELS: src = j.levels + image_index * npix; bytes = npix * 2; break;
         case LFA_LDBG_ROOTS:  src = j.parent + image_index * npix; bytes = npix * 4; break;

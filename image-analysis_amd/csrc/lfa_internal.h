@@ -140,7 +140,11 @@ struct LinesJob {
     int32_t clim;            // clip limit in counts: int(clip(0.05 * kh * kw, 1, None))
     int32_t cap;             // candidate boxes kept per image
     double w0, w1;           // centre and side tap of the 3-tap Gaussian of threshold_local
-    const double* g;         // [n][H*W]     gaussian(image)
+    double wg[5];            // taps 0..4 of the 9-tap sigma-1 Gaussian (wg[4] = centre; symmetric)
+    const uint8_t* images;   // [n] frames, uint8 or uint16 (dtype), C-contiguous
+    int64_t img_bytes;
+    int32_t dtype;
+    double* g;               // [n][H*W]     gaussian(image), kept only for lfa_lines_debug_fetch (null otherwise)
     uint16_t* u;             // [n][H*W]     img_as_uint of the gamma-adjusted image
     uint8_t* binlut;         // [n][65536]   uint16 value -> CLAHE bin
     int32_t* maps;           // [n][nty*ntx][256] tile mappings
@@ -150,7 +154,7 @@ struct LinesJob {
     uint16_t* cls;           // [n][16384]   class per level (0 = background)
     uint16_t* cimg;          // [n][H*W]     class per pixel (k_ccl_init)
     int32_t* parent;         // [n][H*W]     union-find over pixels
-    int32_t* bbox;           // [n][H*W][4]  minr, minc, maxr, maxc at roots
+    int32_t* bbox;           // [n][H*W][4]  at roots: rows down, columns left, columns right of the root (all zero between calls)
     int32_t* cand;           // [n][cap][3]  root, minr, maxr of the boxes that pass the filter
     LfaLinesInfo* info;      // [n]
 };

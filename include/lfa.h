@@ -293,7 +293,8 @@ int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, in
                            const double* w_sigma1, const double* w_local,
                            LfaLineBox* out_boxes, int max_boxes, int32_t* out_counts, LfaLinesInfo* out_info, void* stream);
 
-#define LFA_LDBG_GAUSS   0   /* float64 H*W : sk.filters.gaussian(image)                        (detection.py:166) */
+#define LFA_LDBG_GAUSS   0   /* float64 H*W : sk.filters.gaussian(image)                        (detection.py:166); kept only when
+                                 lfa_set_debug_flags(h, 64) was in force at the call: the product path never writes it */
 #define LFA_LDBG_U16     1   /* uint16  H*W : img_as_uint(adjust_gamma(...)) inside equalize_adapthist (_adapthist.py:73) */
 #define LFA_LDBG_LEVELS  2   /* uint16  H*W : _clahe's result                                   (_adapthist.py:87) */
 #define LFA_LDBG_ROOTS   3   /* int32   H*W : index of the first pixel of the pixel's component, -1 = background (detection.py:184) */

@@ -28,6 +28,7 @@ def capi():
 @pytest.fixture(scope="module")
 def eng(capi):
     e = capi.Engine(device=0, max_h=1536, max_w=2048, max_c=1, max_batch=4)
+    e.set_debug_flags(64)                                           # keep the Gaussian image for lines_debug(LDBG_GAUSS)
     yield e
     e.close()
 
@@ -149,6 +150,20 @@ def test_boxes_of_components_that_spread_left_and_below_their_first_pixel(capi, 
         im[150 + k, 300 - 24 * k - 30:300 - 24 * k] = 255               # staircase: every step further left
     d = _against_oracle(capi, eng, im)
     assert d["labels"].max() > 2
+
+
+def test_without_the_debug_flag_the_gaussian_image_is_not_kept_and_the_results_are_the_same(capi, eng):
+    from image_analysis_amd.synth import synth_lines
+    im = synth_lines(384, 512, 4, np.uint16)
+    boxes, info = eng.detect_lines(im[None])
+    want_levels = eng.lines_debug(0, capi.LDBG_LEVELS, 384, 512)
+    plain = capi.Engine(device=0, max_h=384, max_w=512, max_c=1, max_batch=1)
+    boxes2, info2 = plain.detect_lines(im[None])
+    assert np.array_equal(np.asarray(boxes[0]), np.asarray(boxes2[0])) and info[0].tobytes() == info2[0].tobytes()
+    assert np.array_equal(plain.lines_debug(0, capi.LDBG_LEVELS, 384, 512), want_levels)
+    with pytest.raises(RuntimeError, match="debug flag 64"):
+        plain.lines_debug(0, capi.LDBG_GAUSS, 384, 512)
+    plain.close()
 
 
 def test_drop_in_detect_lines(capi):
