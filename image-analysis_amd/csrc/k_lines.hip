@@ -38,7 +38,7 @@ __device__ __forceinline__ int reflect_half(int i, int n) {         // scipy 're
 // A block stages kFIW columns x (kFTH + 2 + 2R) rows: vertical pass into LDS (one staged column per thread, all rows
 // requested before the first is used, sliding register window), horizontal pass out of LDS and back into it (the
 // Gaussian on kFTH + 2 rows x kFIW - 2R columns), then the local filter on the inner kFTH x (kFIW - 2R - 2) pixels.
-constexpr int kFR = 4, kFTH = 8, kFIW = 256, kFOC = kFIW - 2 * (kFR + 1);
+constexpr int kFR = 4, kFTH = 16, kFIW = 256, kFOC = kFIW - 2 * (kFR + 1);
 
 template <typename PIX>
 __global__ __launch_bounds__(kFIW) void k_lines_front(LinesJob j) {
