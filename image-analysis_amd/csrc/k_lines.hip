@@ -1,7 +1,7 @@
 // k_lines.hip -- detect_lines (LFA-Image_Analysis/detection.py:156-201), SURVEY.md section 8f.3  (gfx950)
 //
-// The reference defines this function and never calls it.  Its stages after the first Gaussian (detection.py:166, done by
-// k_gaussian) are restated here one kernel per dependency -- every stage needs a whole-image scalar of the one before
+// The reference defines this function and never calls it.  Its stages (the first Gaussian, detection.py:166, included:
+// k_lines_front) are restated here one kernel per dependency -- every stage needs a whole-image scalar of the one before
 // (extremes, tile histograms, percentiles), so nothing fuses across them.  Reference arithmetic (SP = /root/reference/
 // image-analysis/lib/python3.10/site-packages):
 //   threshold_local(gaussian, block 3, 'reflect')   SP/skimage/filters/thresholding.py:236-243 -> scipy correlate1d, 3 taps

@@ -287,7 +287,7 @@ typedef struct {
  * w_sigma1: HOST, 9 taps of scipy's Gaussian kernel for sigma 1; w_local: HOST, 3 taps for sigma (3-1)/6; NULL = computed
  *   here with the C library's exp().
  * out_boxes: device, n*max_boxes, in the order the reference appends them; out_counts: device, n; out_info: device, n, or NULL.
- * The workspace of this path (about 34 bytes per pixel) is allocated by the first call that needs it and grows with later
+ * The workspace of this path (about 26 bytes per pixel) is allocated by the first call that needs it and grows with later
  * ones: unlike detect/analyze, this call MAY allocate (and then waits for the device). */
 int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W,
                            const double* w_sigma1, const double* w_local,
