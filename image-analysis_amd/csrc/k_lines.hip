@@ -441,8 +441,32 @@ __global__ __launch_bounds__(1024) void k_lines_levels(LinesJob j) {
     __syncthreads();
     if (t == 0) { uint32_t s = 0; for (int k = 0; k < 1024; ++k) { const uint32_t x = part[k]; part[k] = s; s += x; } }
     __syncthreads();
+    int cl[16], first = 16384;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) cls[t * 16 + k] = (v[k] == 0.0) ? (uint16_t)0 : (uint16_t)(part[t] + loc[k]);
+    for (int k = 0; k < 16; ++k) {
+        cl[k] = (v[k] == 0.0) ? 0 : (int)(part[t] + loc[k]);
+        cls[t * 16 + k] = (uint16_t)cl[k];
+        if (cl[k] > 0 && first == 16384) first = t * 16 + k;
+    }
+    // The table is almost always "0 up to a level a, then one new class per level, then constant" (both rescales are
+    // strictly increasing between their clip points): k_ccl_init then computes min(max(level - a, 0), m) instead of
+    // looking the class up.  Checked here entry by entry; where it does not hold (two levels whose floats collide) the
+    // table is used.
+    if (t == 0) { s_level[0] = 16384; s_level[1] = (int)(part[1023]); s_level[2] = 1; }
+    __syncthreads();
+    if (first < 16384) atomicMin(&s_level[0], first);
+    if (t == 1023) s_level[1] += (int)f;
+    __syncthreads();
+    const int ca = s_level[0] - 1, cm = s_level[1];
+    bool same = true;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) same = same && cl[k] == min(max(t * 16 + k - ca, 0), cm);
+    if (!same) s_level[2] = 0;
+    __syncthreads();
+    if (t == 0) {
+        int32_t* fn = j.clsfn + 4 * img;
+        fn[0] = ca; fn[1] = cm; fn[2] = (s_level[2] && !j.force_table) ? 1 : 0; fn[3] = 0;
+    }
 }
 
 // ---- stage 7: components of equal class, 8-connected ------------------------------------------------------------------------
@@ -464,18 +488,14 @@ __device__ __forceinline__ void ccl_union(int32_t* parent, int a, int b) {
 }
 
 __global__ __launch_bounds__(256) void k_ccl_init(LinesJob j) {
-    __shared__ __align__(16) uint16_t s_cls[16384];                                    // the image's class table: the gather below stays on the CU
     const int img = blockIdx.y;
     const int64_t npix = (int64_t)j.H * j.W;
     int32_t* __restrict__ parent = j.parent + (int64_t)img * npix;
     const uint16_t* __restrict__ lv = j.levels + (int64_t)img * npix;
+    const uint16_t* __restrict__ cls = j.cls + (int64_t)img * 16384;
     uint16_t* __restrict__ cimg = j.cimg + (int64_t)img * npix;
-    {
-        const uint4* src = (const uint4*)(j.cls + (int64_t)img * 16384);
-        uint4* dst = (uint4*)s_cls;
-        for (int k = threadIdx.x; k < 2048; k += 256) dst[k] = src[k];
-    }
-    __syncthreads();
+    const int cls_a = j.clsfn[4 * img], cls_m = j.clsfn[4 * img + 1];
+    const bool cls_fn = j.clsfn[4 * img + 2] != 0;                      // k_lines_levels: class = min(max(level - a, 0), m)
     // Pixels of one class that sit side by side in a wave's 64 (one row) start out linked to the first of them: the long
     // horizontal runs of a line never form a chain of single links, and k_ccl_merge only joins runs.
     const int lane = threadIdx.x & 63;
@@ -488,7 +508,8 @@ __global__ __launch_bounds__(256) void k_ccl_init(LinesJob j) {
         for (int k = 0; k < 4; ++k) {
             const int64_t p = p0 + k * stride;
             const bool valid = p < npix;                                 // (a valid lane's lower lanes are valid too)
-            const int c = valid ? (int)s_cls[l[k] & 16383] : 0;
+            const int lev = l[k] & 16383;
+            const int c = !valid ? 0 : (cls_fn ? min(max(lev - cls_a, 0), cls_m) : (int)cls[lev]);
             const int x = (int)((uint32_t)p % (uint32_t)j.W);           // (p < 2^30)
             const int cleft = __shfl_up(c, 1);
             const unsigned long long starts = __ballot(lane == 0 || x == 0 || c != cleft);
@@ -609,26 +630,45 @@ __global__ __launch_bounds__(256) void k_ccl_collect(LinesJob j) {
     const double min_area = (double)j.W * ((double)j.H * 0.0065), max_area = (double)j.W * ((double)j.H * 0.04);   // :159-160
     int32_t* cand = j.cand + (int64_t)img * j.cap * 3;
     // (a root no pixel points to is a single pixel: one by one, never wider than tall, never a candidate)
+    auto visit = [&](int64_t p) {
+        const int4 e = bbox[p];
+        bbox[p] = make_int4(0, 0, 0, 0);                                 // the table is all zero again when the call ends
+        const int yr = (int)((uint32_t)p / (uint32_t)j.W), xr = (int)((uint32_t)p - (uint32_t)yr * (uint32_t)j.W);
+        const int minr = yr, maxr = yr + max(e.x, 1), minc = xr - e.y, maxc = xr + max(e.z, 1);
+        const int64_t area = (int64_t)(maxc - minc) * (maxr - minr);
+        // wider than tall and min_area < area < max_area: the box is widened to the whole image width and kept (:193-200)
+        if ((maxc - minc) > (maxr - minr) && (double)area > min_area && (double)area < max_area) {
+            const int k2 = atomicAdd(&j.info[img].n_boxes, 1);
+            if (k2 < j.cap) { cand[3 * k2] = (int)p; cand[3 * k2 + 1] = minr; cand[3 * k2 + 2] = maxr; }
+        }
+    };
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if ((npix & 7) == 0) {                                               // every frame's flags start at a multiple of 16 bytes
+        const uint4* __restrict__ c8 = (const uint4*)cimg;
+        const int64_t n8 = npix >> 3;
+        for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < n8; q0 += 2 * stride) {
+            uint4 f[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int64_t q = q0 + k * stride; f[k] = q < n8 ? c8[q] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint32_t w[4] = {f[k].x, f[k].y, f[k].z, f[k].w};
+                const int64_t p = (q0 + k * stride) << 3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if ((w[i] & 0xffffu) == 0xffffu) visit(p + 2 * i);
+                    if ((w[i] >> 16) == 0xffffu) visit(p + 2 * i + 1);
+                }
+            }
+        }
+        return;
+    }
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < npix; p0 += 4 * stride) {
         int f[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const int64_t p = p0 + k * stride; f[k] = p < npix ? cimg[p] : 0; }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (f[k] != 0xffff) continue;
-            const int64_t p = p0 + k * stride;
-            const int4 e = bbox[p];
-            bbox[p] = make_int4(0, 0, 0, 0);                             // the table is all zero again when the call ends
-            const int yr = (int)((uint32_t)p / (uint32_t)j.W), xr = (int)((uint32_t)p - (uint32_t)yr * (uint32_t)j.W);
-            const int minr = yr, maxr = yr + max(e.x, 1), minc = xr - e.y, maxc = xr + max(e.z, 1);
-            const int64_t area = (int64_t)(maxc - minc) * (maxr - minr);
-            // wider than tall and min_area < area < max_area: the box is widened to the whole image width and kept (:193-200)
-            if ((maxc - minc) > (maxr - minr) && (double)area > min_area && (double)area < max_area) {
-                const int k2 = atomicAdd(&j.info[img].n_boxes, 1);
-                if (k2 < j.cap) { cand[3 * k2] = (int)p; cand[3 * k2 + 1] = minr; cand[3 * k2 + 2] = maxr; }
-            }
-        }
+        for (int k = 0; k < 4; ++k) if (f[k] == 0xffff) visit(p0 + k * stride);
     }
 }
 

@@ -163,13 +163,13 @@ struct LfaContext {
     int win_hint = 0;                      // longest analysis window of the last completed call (rows), 0 = unknown
     // detect_lines workspace (lfa_detect_lines_batch), allocated by the first call that needs it
     bool ln_bbox_dirty = false;
-    Buf ln_g, ln_u, ln_binlut, ln_maps, ln_levels, ln_lhist, ln_lval, ln_cls, ln_cimg, ln_parent, ln_bbox, ln_cand, ln_info;
+    Buf ln_g, ln_u, ln_binlut, ln_maps, ln_levels, ln_lhist, ln_lval, ln_cls, ln_clsfn, ln_cimg, ln_parent, ln_bbox, ln_cand, ln_info;
     lfa::LinesJob lines_last{};
     bool have_lines = false;
     std::vector<Buf*> all() {
         std::vector<Buf*> v = ws.all();
         v.push_back(&lut8); v.push_back(&lut16); v.push_back(&plane_stats); v.push_back(&roi_idx);
-        for (Buf* b : {&ln_g, &ln_u, &ln_binlut, &ln_maps, &ln_levels, &ln_lhist, &ln_lval, &ln_cls, &ln_cimg, &ln_parent, &ln_bbox, &ln_cand, &ln_info})
+        for (Buf* b : {&ln_g, &ln_u, &ln_binlut, &ln_maps, &ln_levels, &ln_lhist, &ln_lval, &ln_cls, &ln_clsfn, &ln_cimg, &ln_parent, &ln_bbox, &ln_cand, &ln_info})
             v.push_back(b);
         return v;
     }
@@ -757,7 +757,7 @@ int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, in
     const bool keep_gauss = (h->debug_flags & 64) != 0;                           // lfa_lines_debug_fetch(LFA_LDBG_GAUSS) needs it
     if ((keep_gauss && (rc = ensure(h->ln_g, N * npix * 8))) || (rc = ensure(h->ln_u, N * npix * 2)) || (rc = ensure(h->ln_binlut, N * 65536)) ||
         (rc = ensure(h->ln_maps, N * (size_t)j.nty * j.ntx * 256 * 4)) || (rc = ensure(h->ln_levels, N * npix * 2)) ||
-        (rc = ensure(h->ln_lhist, N * 16384 * 4)) || (rc = ensure(h->ln_lval, N * 16384 * 8)) || (rc = ensure(h->ln_cls, N * 16384 * 2)) || (rc = ensure(h->ln_cimg, N * npix * 2)) ||
+        (rc = ensure(h->ln_lhist, N * 16384 * 4)) || (rc = ensure(h->ln_lval, N * 16384 * 8)) || (rc = ensure(h->ln_cls, N * 16384 * 2)) || (rc = ensure(h->ln_clsfn, N * 16)) || (rc = ensure(h->ln_cimg, N * npix * 2)) ||
         (rc = ensure(h->ln_parent, N * npix * 4)) ||
         (rc = ensure(h->ln_cand, N * (size_t)j.cap * 12)) || (rc = ensure(h->ln_info, N * sizeof(LfaLinesInfo))))
         return rc;
@@ -767,7 +767,7 @@ int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, in
     if ((rc = ensure(h->ln_bbox, N * npix * 16))) return rc;
     const bool clear_bbox = h->ln_bbox.p != bbox_was || h->ln_bbox_dirty;
     j.g = keep_gauss ? (double*)h->ln_g.p : nullptr; j.u = (uint16_t*)h->ln_u.p; j.binlut = (uint8_t*)h->ln_binlut.p; j.maps = (int32_t*)h->ln_maps.p;
-    j.levels = (uint16_t*)h->ln_levels.p; j.lhist = (uint32_t*)h->ln_lhist.p; j.lval = (double*)h->ln_lval.p; j.cls = (uint16_t*)h->ln_cls.p; j.cimg = (uint16_t*)h->ln_cimg.p;
+    j.levels = (uint16_t*)h->ln_levels.p; j.lhist = (uint32_t*)h->ln_lhist.p; j.lval = (double*)h->ln_lval.p; j.cls = (uint16_t*)h->ln_cls.p; j.clsfn = (int32_t*)h->ln_clsfn.p; j.force_table = (h->debug_flags & 128) ? 1 : 0; j.cimg = (uint16_t*)h->ln_cimg.p;
     j.parent = (int32_t*)h->ln_parent.p; j.bbox = (int32_t*)h->ln_bbox.p; j.cand = (int32_t*)h->ln_cand.p; j.info = (LfaLinesInfo*)h->ln_info.p;
     j.images = (const uint8_t*)images; j.img_bytes = (int64_t)H * W * (dtype == LFA_U16 ? 2 : 1); j.dtype = dtype;
     for (int k = 0; k < 5; ++k) j.wg[k] = w9[k];

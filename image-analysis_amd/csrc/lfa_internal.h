@@ -152,6 +152,8 @@ struct LinesJob {
     uint32_t* lhist;         // [n][16384]   histogram of levels, then its inclusive prefix
     double* lval;            // [n][16384]   final float value per level
     uint16_t* cls;           // [n][16384]   class per level (0 = background)
+    int32_t* clsfn;          // [n][4]       a, m, valid: class = min(max(level - a, 0), m) where the table has that form
+    int32_t force_table;     // debug flag 128: always look the class up
     uint16_t* cimg;          // [n][H*W]     class per pixel (k_ccl_init)
     int32_t* parent;         // [n][H*W]     union-find over pixels
     int32_t* bbox;           // [n][H*W][4]  at roots: rows down, columns left, columns right of the root (all zero between calls)

@@ -166,6 +166,24 @@ def test_without_the_debug_flag_the_gaussian_image_is_not_kept_and_the_results_a
     plain.close()
 
 
+def test_class_lookup_and_class_function_agree(capi, eng):
+    """k_ccl_init computes a pixel's class from its level where the class table has the usual shape; debug flag 128 makes it
+    look the class up instead: same labels, same boxes (odd pixel count: the scalar path of k_ccl_collect too)"""
+    from image_analysis_amd.synth import synth_lines
+    for im in (synth_lines(384, 512, 11, np.uint8), synth_lines(301, 517, 12, np.uint8)):
+        H, W = im.shape
+        boxes, info = eng.detect_lines(im[None])
+        roots = eng.lines_debug(0, capi.LDBG_ROOTS, H, W)
+        eng.set_debug_flags(64 | 128)
+        try:
+            boxes2, info2 = eng.detect_lines(im[None])
+            roots2 = eng.lines_debug(0, capi.LDBG_ROOTS, H, W)
+        finally:
+            eng.set_debug_flags(64)
+        assert len(boxes[0]) > 0 and np.array_equal(np.asarray(boxes[0]), np.asarray(boxes2[0]))
+        assert info[0].tobytes() == info2[0].tobytes() and np.array_equal(roots, roots2)
+
+
 def test_drop_in_detect_lines(capi):
     import image_analysis_amd.detection as detection
     from oracle import lines_oracle as L
