@@ -580,41 +580,69 @@ __global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
     // A wave takes 64 consecutive pixels per step (wave-uniform loop).  Pixels of one component that sit side by side in a
     // wave would all hit the same words of their root: they are combined in the wave first (one leader per distinct
     // root, DPP reductions) -- per-pixel atomics on the few large components cost 1.4 of this kernel's 1.7 ms.
+    // one step of the whole wave: lane's pixel p with the parent entry `up` it loaded (-1: background or no pixel)
+    auto step = [&](int64_t p, int up) {
+        int r = -1, y = 0, x = 0;
+        bool need = false;
+        if (up == (int)p) ++roots;                                       // (most components of a CLAHE'd frame are single pixels)
+        else if (up >= 0) {
+            r = ccl_find(parent, up);
+            parent[p] = r;                                               // (others only ever point to smaller indices)
+            y = (int)((uint32_t)p / (uint32_t)j.W); x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);
+            need = true;
+        }
+        unsigned long long todo = __ballot(need);
+        while (todo) {
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const int lr = __shfl(r, leader);
+            const bool mine = need && r == lr;
+            const int x0 = wave_min_i32(mine ? x : 0x7fffffff);
+            const int y1 = wave_max_i32(mine ? y + 1 : -1), x1 = wave_max_i32(mine ? x + 1 : -1);
+            if (lane == leader) {
+                const int yr = (int)((uint32_t)lr / (uint32_t)j.W), xr = (int)((uint32_t)lr - (uint32_t)yr * (uint32_t)j.W);
+                int32_t* e = bbox + 4 * (int64_t)lr;
+                if (y1 - yr > 1) atomicMax(&e[0], y1 - yr);              // maxr - root row
+                if (xr - x0 > 0) atomicMax(&e[1], xr - x0);              // root column - minc
+                if (x1 - xr > 1) atomicMax(&e[2], x1 - xr);              // maxc - root column
+                cimg[lr] = (uint16_t)0xffff;
+            }
+            todo &= ~__ballot(mine);
+        }
+    };
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t pb0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); pb0 < npix; pb0 += 4 * stride) {
-        int ups[4];                                                      // four segments per step: their loads go out together
+    if ((npix & 3) == 0) {
+        // 16-byte loads: a lane takes four neighbouring pixels, a wave 256 per load, two loads in flight.  Almost every load
+        // holds only background and single-pixel components, which need nothing but the count; a wave in which any lane
+        // holds a pixel that points elsewhere goes through the four pixels of its lanes one after the other.
+        const int4* __restrict__ p4 = (const int4*)parent;
+        const int64_t n4 = npix >> 2;
+        for (int64_t qb = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); qb < n4; qb += 2 * stride) {
+            int4 ups[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const int64_t p = pb0 + k * stride + lane; ups[k] = p < npix ? parent[p] : -1; }
+            for (int k = 0; k < 2; ++k) { const int64_t q = qb + k * stride + lane; ups[k] = q < n4 ? p4[q] : make_int4(-1, -1, -1, -1); }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int64_t p = pb0 + k * stride + lane;
-            const int up = ups[k];                                       // (-1: background, k_ccl_init; this lane's own entry: only it writes it)
-            int r = -1, y = 0, x = 0;
-            bool need = false;
-            if (up == (int)p) ++roots;                                   // (most components of a CLAHE'd frame are single pixels)
-            else if (up >= 0) {
-                r = ccl_find(parent, up);
-                parent[p] = r;                                           // (others only ever point to smaller indices)
-                y = (int)((uint32_t)p / (uint32_t)j.W); x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);
-                need = true;
-            }
-            unsigned long long todo = __ballot(need);
-            while (todo) {
-                const int leader = __ffsll((unsigned long long)todo) - 1;
-                const int lr = __shfl(r, leader);
-                const bool mine = need && r == lr;
-                const int x0 = wave_min_i32(mine ? x : 0x7fffffff);
-                const int y1 = wave_max_i32(mine ? y + 1 : -1), x1 = wave_max_i32(mine ? x + 1 : -1);
-                if (lane == leader) {
-                    const int yr = (int)((uint32_t)lr / (uint32_t)j.W), xr = (int)((uint32_t)lr - (uint32_t)yr * (uint32_t)j.W);
-                    int32_t* e = bbox + 4 * (int64_t)lr;
-                    if (y1 - yr > 1) atomicMax(&e[0], y1 - yr);          // maxr - root row
-                    if (xr - x0 > 0) atomicMax(&e[1], xr - x0);          // root column - minc
-                    if (x1 - xr > 1) atomicMax(&e[2], x1 - xr);          // maxc - root column
-                    cimg[lr] = (uint16_t)0xffff;
+            for (int k = 0; k < 2; ++k) {
+                const int64_t p = (qb + k * stride + lane) << 2;
+                const int u4[4] = {ups[k].x, ups[k].y, ups[k].z, ups[k].w};
+                bool any = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) any = any || (u4[i] >= 0 && u4[i] != (int)(p + i));
+                if (__ballot(any)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) step(p + i, u4[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) roots += (u4[i] == (int)(p + i)) ? 1u : 0u;
                 }
-                todo &= ~__ballot(mine);
             }
+        }
+    } else {
+        for (int64_t pb0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); pb0 < npix; pb0 += 4 * stride) {
+            int ups[4];                                                  // four segments per step: their loads go out together
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int64_t p = pb0 + k * stride + lane; ups[k] = p < npix ? parent[p] : -1; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) step(pb0 + k * stride + lane, ups[k]);
         }
     }
     roots = wave_sum_u32(roots);
