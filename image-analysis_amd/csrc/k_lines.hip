@@ -522,12 +522,70 @@ __global__ __launch_bounds__(256) void k_ccl_init(LinesJob j) {
     }
 }
 
+// Only edges that no other link already implies are joined: the left neighbour across a wave boundary of k_ccl_init (inside
+// one it linked the run), the upper neighbour where a run's overlap with the run above starts (the pixel to the left makes
+// the same join otherwise), a diagonal one when neither the upper nor the left pixel carries it.  The components are the
+// same, with far fewer walks to a root.  c: the pixel's class (not 0); cl, cu, cul, cur: left, upper, upper left, upper
+// right neighbour's class, 0 where there is none.
+__device__ __forceinline__ void ccl_join(int32_t* parent, int p, int W, int c, int cl, int cu, int cul, int cur) {
+    if (cl == c && (p & 63) == 0) ccl_union(parent, p, p - 1);
+    if (cu == c) { if (!(cl == c && cul == c)) ccl_union(parent, p, p - W); }
+    else {
+        if (cul == c && cl != c) ccl_union(parent, p, p - W - 1);
+        if (cur == c) ccl_union(parent, p, p - W + 1);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ccl_merge(LinesJob j) {
     const int img = blockIdx.y;
     const int64_t npix = (int64_t)j.H * j.W;
     const uint16_t* __restrict__ cimg = j.cimg + (int64_t)img * npix;
     int32_t* parent = j.parent + (int64_t)img * npix;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if ((j.W & 7) == 0) {
+        // rows of a multiple of 8 pixels: a lane takes 8 neighbouring pixels of one row with one 16-byte load, the 8 above
+        // them with another and three single classes at the ends (left, upper left, upper right); two such groups per step
+        const uint4* __restrict__ c8 = (const uint4*)cimg;
+        const int64_t n8 = npix >> 3;
+        const int W8 = j.W >> 3;
+        for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < n8; q0 += 2 * stride) {
+            uint4 cur[2], abv[2];
+            int lft[2], ul[2], ur[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { const int64_t q = q0 + k * stride; cur[k] = q < n8 ? c8[q] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                abv[k] = make_uint4(0, 0, 0, 0); lft[k] = ul[k] = ur[k] = 0;
+                if (cur[k].x | cur[k].y | cur[k].z | cur[k].w) {
+                    const int64_t q = q0 + k * stride, p = q << 3;
+                    const int y = (int)((uint32_t)p / (uint32_t)j.W), x = (int)((uint32_t)p - (uint32_t)y * (uint32_t)j.W);   // (p < 2^30)
+                    if (x > 0) lft[k] = cimg[p - 1];
+                    if (y > 0) {
+                        abv[k] = c8[q - W8];
+                        if (x > 0) ul[k] = cimg[p - j.W - 1];
+                        if (x + 8 < j.W) ur[k] = cimg[p - j.W + 8];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!(cur[k].x | cur[k].y | cur[k].z | cur[k].w)) continue;
+                const int p = (int)((q0 + k * stride) << 3);
+                const uint32_t cw[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w}, aw[4] = {abv[k].x, abv[k].y, abv[k].z, abv[k].w};
+                int c[9], a[10];                                         // c[0]: left of the group; a[0], a[9]: upper left / right of it
+                c[0] = lft[k]; a[0] = ul[k]; a[9] = ur[k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    c[1 + 2 * i] = (int)(cw[i] & 0xffffu); c[2 + 2 * i] = (int)(cw[i] >> 16);
+                    a[1 + 2 * i] = (int)(aw[i] & 0xffffu); a[2 + 2 * i] = (int)(aw[i] >> 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (c[i + 1]) ccl_join(parent, p + i, j.W, c[i + 1], c[i], a[i + 1], a[i], a[i + 2]);
+            }
+        }
+        return;
+    }
     for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < npix; p0 += 4 * stride) {
         // four pixels per step; all their loads are issued before the first walk to a root
         int c[4], cl[4], cu[4], cul[4], cur[4];
@@ -546,21 +604,9 @@ __global__ __launch_bounds__(256) void k_ccl_merge(LinesJob j) {
                 if (hasu && hasr) cur[k] = cimg[q + 1];
             }
         }
-        // Only edges that no other link already implies are joined: the left neighbour across a wave boundary (inside a
-        // wave k_ccl_init linked the run), the upper neighbour where a run's overlap with the run above starts (the pixel
-        // to the left makes the same join otherwise), a diagonal one when neither the upper nor the left pixel carries
-        // it.  The components are the same, with far fewer walks to a root.
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!c[k]) continue;
-            const int p = (int)(p0 + k * stride), q = p - j.W;
-            if (cl[k] == c[k] && (p & 63) == 0) ccl_union(parent, p, p - 1);
-            if (cu[k] == c[k]) { if (!(cl[k] == c[k] && cul[k] == c[k])) ccl_union(parent, p, q); }
-            else {
-                if (cul[k] == c[k] && cl[k] != c[k]) ccl_union(parent, p, q - 1);
-                if (cur[k] == c[k]) ccl_union(parent, p, q + 1);
-            }
-        }
+        for (int k = 0; k < 4; ++k)
+            if (c[k]) ccl_join(parent, (int)(p0 + k * stride), j.W, c[k], cl[k], cu[k], cul[k], cur[k]);
     }
 }
 
