@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Extended detect_lines fuzz on the GPU box (not a pytest test: minutes of oracle time): random frames of random shape --
+rows of a multiple of 8 pixels and not, pixel counts that are / are not multiples of 4 and 8 (the 16-byte-load paths of the
+labelling kernels), shapes below one CLAHE tile -- every intermediate (uint16 image, levels, roots) and the boxes against
+oracle/lines_oracle.py.  usage: python tools/lines_fuzz.py [cases] [seed]"""
+import importlib.util
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    import image_analysis_amd._capi as capi
+    from oracle import lines_oracle as L
+    fz = _load(os.path.join(ROOT, "tests", "test_gpu_fuzz_round2.py"), "fz")
+    tl = _load(os.path.join(ROOT, "tests", "test_gpu_lines.py"), "tl")
+    eng = capi.Engine(device=0, max_h=320, max_w=320, max_c=1, max_batch=1)
+    eng.set_debug_flags(64)
+    rng = np.random.default_rng(seed)
+    t0 = time.time()
+    refused = boxes = 0
+    for it in range(cases):
+        H, W = int(rng.integers(2, 300)), int(rng.integers(2, 300))
+        if it % 3 == 0:
+            W = max(8, W & ~7)
+        if it % 5 == 0:
+            H = max(4, H & ~3)
+        im = fz._frame(rng, H, W, np.uint8 if it % 2 else np.uint16)
+        if it % 7 == 0:                                             # a few long bright bars: components that span waves and rows
+            for _ in range(int(rng.integers(1, 4))):
+                r = int(rng.integers(0, H)); h = int(rng.integers(1, max(2, H // 8)))
+                im[r:r + h, int(rng.integers(0, max(1, W // 4))):] = im.max()
+        try:
+            L.lines_debug(im)
+        except ValueError:
+            refused += 1
+            try:
+                eng.detect_lines(im[None])
+            except Exception:
+                pass
+            continue
+        if it % 11 == 0:
+            eng.set_debug_flags(64 | 128)
+        d = tl._against_oracle(capi, eng, im)
+        eng.set_debug_flags(64)
+        boxes += len(d["strips"])
+        if it % 25 == 0:
+            print(f"case {it}: {H}x{W} ok, {boxes} boxes so far, {time.time() - t0:.0f} s", flush=True)
+    print(f"lines fuzz ok: {cases} cases, {refused} refused by the reference as well, {boxes} boxes, {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
