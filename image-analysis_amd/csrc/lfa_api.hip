@@ -763,9 +763,9 @@ int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, in
         return rc;
     // the box extents table is all zero between calls (k_ccl_boxes / k_ccl_collect, k_lines.hip): cleared when it is
     // allocated, and again after a call whose launches did not all go out
-    const void* bbox_was = h->ln_bbox.p;
+    const size_t bbox_was = h->ln_bbox.bytes;                                     // (not the pointer: a larger block may start where the old one did)
     if ((rc = ensure(h->ln_bbox, N * npix * 16))) return rc;
-    const bool clear_bbox = h->ln_bbox.p != bbox_was || h->ln_bbox_dirty;
+    const bool clear_bbox = h->ln_bbox.bytes != bbox_was || h->ln_bbox_dirty;
     j.g = keep_gauss ? (double*)h->ln_g.p : nullptr; j.u = (uint16_t*)h->ln_u.p; j.binlut = (uint8_t*)h->ln_binlut.p; j.maps = (int32_t*)h->ln_maps.p;
     j.levels = (uint16_t*)h->ln_levels.p; j.lhist = (uint32_t*)h->ln_lhist.p; j.lval = (double*)h->ln_lval.p; j.cls = (uint16_t*)h->ln_cls.p; j.clsfn = (int32_t*)h->ln_clsfn.p; j.force_table = (h->debug_flags & 128) ? 1 : 0; j.cimg = (uint16_t*)h->ln_cimg.p;
     j.parent = (int32_t*)h->ln_parent.p; j.bbox = (int32_t*)h->ln_bbox.p; j.cand = (int32_t*)h->ln_cand.p; j.info = (LfaLinesInfo*)h->ln_info.p;

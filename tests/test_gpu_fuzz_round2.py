@@ -43,6 +43,21 @@ def test_detect_lines_fuzz():
     assert nonempty >= 5
 
 
+def test_detect_lines_fuzz_on_one_handle_with_growing_frames():
+    """tools/lines_fuzz.py, 120 cases on ONE handle: every intermediate against the oracle on frames of random shape (rows of
+    a multiple of 8 pixels or not, bright bars that span waves and rows, the class lookup forced now and then).  The handle's
+    workspace grows as larger frames arrive: the box extents table must be cleared whenever it is allocated anew -- also when
+    the larger block starts at the old block's address, which is how this sequence (seed 1, cases 85 and 100) once found
+    stale extents."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lines_fuzz.py")
+    spec = importlib.util.spec_from_file_location("lines_fuzz", path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.run(120, 1) > 20
+
+
 def test_uint16_colour_detect_fuzz():
     import image_analysis_amd.detection as detection
     from oracle import lfa_oracle as O

@@ -12,6 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def _load(path, name):
@@ -21,9 +22,7 @@ def _load(path, name):
     return m
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def run(cases, seed):
     import image_analysis_amd._capi as capi
     from oracle import lines_oracle as L
     fz = _load(os.path.join(ROOT, "tests", "test_gpu_fuzz_round2.py"), "fz")
@@ -55,13 +54,30 @@ def main():
             continue
         if it % 11 == 0:
             eng.set_debug_flags(64 | 128)
-        d = tl._against_oracle(capi, eng, im)
+        try:
+            bx0, info0 = eng.detect_lines(im[None])
+            want0 = L.lines_debug(im)["strips"]
+            got0 = [[int(b["minr"]), int(b["maxr"]), int(b["minc"]), int(b["maxc"])] for b in bx0[0]]
+            if got0 != want0:
+                print("FIRST CALL case", it, H, W, "got", got0[:8], "want", want0[:8], info0[0], flush=True)
+            d = tl._against_oracle(capi, eng, im)
+        except AssertionError:
+            bx, info = eng.detect_lines(im[None])
+            want = L.lines_debug(im)["strips"]
+            print("MISMATCH case", it, H, W, im.dtype, "flags128" if it % 11 == 0 else "", flush=True)
+            print(" got ", [[int(b["minr"]), int(b["maxr"])] for b in bx[0]][:12], len(bx[0]), info[0])
+            print(" want", [w[:2] for w in want][:12], len(want), flush=True)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            np.save(os.path.join(ROOT, "gpurun_out", f"lines_fuzz_fail_{seed}_{it}.npy"), im)
+            raise
         eng.set_debug_flags(64)
         boxes += len(d["strips"])
         if it % 25 == 0:
             print(f"case {it}: {H}x{W} ok, {boxes} boxes so far, {time.time() - t0:.0f} s", flush=True)
     print(f"lines fuzz ok: {cases} cases, {refused} refused by the reference as well, {boxes} boxes, {time.time() - t0:.0f} s")
+    eng.close()
+    return boxes
 
 
 if __name__ == "__main__":
-    main()
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
