@@ -149,17 +149,23 @@ def point_op_lut(dtype, gamma_level=1, low_exposure=None, high_exposure=None, in
     return np.ascontiguousarray(v, dtype=dt)
 
 
-def detect_gray_variant():
-    """Which rounding order `rgb @ coeffs` has in THIS host's numpy/BLAS (include/lfa.h LFA_GRAY_*).
+def detect_gray_variant(width=64):
+    """Which rounding order `rgb @ coeffs` has in THIS host's numpy/BLAS for images `width` pixels wide (include/lfa.h
+    LFA_GRAY_*).
 
-    Evaluates the candidate orders with exact float64 arithmetic on random triples and returns the first that
-    reproduces numpy's matmul on all of them (colorconv.py:876-877).  Raises if none does."""
+    numpy evaluates `(H, W, 3) @ (3,)` row by row of the image: a matrix-vector product of a W x 3 matrix (BLAS gemv), and
+    for W == 1 a plain dot product -- two routines with their own order of operations and use of fused multiply-adds, so
+    the order is a function of the width.  Evaluates the candidate orders with exact float64 arithmetic on random
+    triples laid out as rows of that width and returns the first that reproduces numpy's matmul on all of them
+    (colorconv.py:876-877).  Raises if none does."""
     import math
+    width = max(1, int(width))
+    rows_n = max(2, -(-1024 // width))
     rng = np.random.default_rng(12345)
-    px = rng.integers(0, 256, size=(4096, 3), dtype=np.uint8)
+    px = rng.integers(0, 256, size=(rows_n * width, 3), dtype=np.uint8)
     x = np.multiply(px, 1.0 / 255, dtype=np.float64)
     c = np.array([0.2125, 0.7154, 0.0721])
-    want = (x.reshape(64, 64, 3) @ c).reshape(-1)
+    want = (x.reshape(rows_n, width, 3) @ c).reshape(-1)
     fma = getattr(math, "fma", None)
     if fma is None:
         libm = C.CDLL("libm.so.6")
@@ -179,17 +185,18 @@ def detect_gray_variant():
     for v, f in enumerate(forms):
         if all(f(*r) == w for r, w in zip(rows, want)):
             return v
-    raise RuntimeError("this host's numpy matmul matches none of the known rgb2gray rounding orders")
+    raise RuntimeError(f"this host's numpy matmul matches none of the known rgb2gray rounding orders for images {width} pixels wide")
 
 
-_GRAY_VARIANT = None
+_GRAY_VARIANT = {}
 
 
-def host_gray_variant():
-    global _GRAY_VARIANT
-    if _GRAY_VARIANT is None:
-        _GRAY_VARIANT = detect_gray_variant()
-    return _GRAY_VARIANT
+def host_gray_variant(width=64):
+    """detect_gray_variant(width), remembered per width."""
+    width = max(1, int(width))
+    if width not in _GRAY_VARIANT:
+        _GRAY_VARIANT[width] = detect_gray_variant(width)
+    return _GRAY_VARIANT[width]
 
 
 # ---- torch hand-off ----------------------------------------------------------------------------------------------------
@@ -266,6 +273,7 @@ class Engine:
             l16 = numpy_gamma_lut_u16()
             _check(lib.lfa_set_gamma_lut(self._h, LFA_U8, l8.ctypes.data, 256))
             _check(lib.lfa_set_gamma_lut(self._h, LFA_U16, l16.ctypes.data, 65536))
+        self._gray_fixed = gray_variant is not None                  # a caller's choice stays; otherwise it follows the image width
         self.gray_variant = host_gray_variant() if gray_variant is None else int(gray_variant)
         _check(lib.lfa_set_gray_variant(self._h, self.gray_variant))
 
@@ -281,7 +289,17 @@ class Engine:
             pass
 
     # -- raw calls on device tensors (uint8 byte tensors) --------------------------------------------------------------
+    def _gray_for(self, W, Cc):
+        """rgb2gray's rounding order in the host's numpy depends on the image width (detect_gray_variant): set the handle to
+        the one the reference would get for this call's images."""
+        if Cc == 3 and not self._gray_fixed:
+            v = host_gray_variant(W)
+            if v != self.gray_variant:
+                _check(lib.lfa_set_gray_variant(self._h, v))
+                self.gray_variant = v
+
     def detect_raw(self, images_t, dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length, max_strips):
+        self._gray_for(W, Cc)
         strips = dev_bytes(n * max_strips * STRIP_DT.itemsize, self.device)
         counts = dev_bytes(n * 4, self.device)
         info = dev_bytes(n * INFO_DT.itemsize, self.device)
@@ -292,6 +310,7 @@ class Engine:
 
     def analyze_raw(self, images_t, dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length, max_strips, stride):
         torch = _torch()
+        self._gray_for(W, Cc)
         strips = dev_bytes(n * max_strips * STRIP_DT.itemsize, self.device)
         counts = dev_bytes(n * 4, self.device)
         info = dev_bytes(n * INFO_DT.itemsize, self.device)

@@ -136,7 +136,11 @@ int lfa_version(void);
  * tables built with the host's numpy so that they carry that numpy's pow() bits. */
 int lfa_set_gamma_lut(LfaHandle h, int dtype, const void* lut, int n);
 
-/* Select the rounding order of rgb2gray's matmul (LFA_GRAY_*), colorconv.py:876-877. */
+/* Select the rounding order of rgb2gray's matmul (LFA_GRAY_*), colorconv.py:876-877.  numpy evaluates `rgb @ coeffs` row by
+ * row of the image -- a BLAS matrix-vector product, and a dot product when the image is one pixel wide -- so the order
+ * the reference gets can depend on the image width: the Python binding probes the host's numpy per width
+ * (_capi.detect_gray_variant) and calls this before a detect / analyze call whose images need another order.  The
+ * value is read when a call is made; calls already enqueued keep theirs. */
 int lfa_set_gray_variant(LfaHandle h, int variant);
 
 /* Test hook (no counterpart in the reference).  bit0: colour images take the float64 compare path even when the exact

@@ -272,3 +272,13 @@ def test_numpy_float_box_sum_order_is_what_k_box_sums_restates():
             for x in range(w):
                 a = a + v[y, x]
         assert (a / (h * w)).tobytes() == np.mean(v, axis=(0, 1)).tobytes(), (h, w)
+
+
+def test_gray_variant_is_probed_per_image_width():
+    """`rgb @ coeffs` is a dot product for one-pixel-wide images and a matrix-vector product otherwise: the binding asks the
+    host's numpy for the rounding order of each width it meets (and finds one of the known orders for every width)."""
+    import importlib
+    capi = importlib.import_module("image_analysis_amd._capi")
+    got = {w: capi.host_gray_variant(w) for w in (1, 2, 3, 8, 17, 64, 250)}
+    assert all(0 <= v <= 5 for v in got.values())
+    assert capi.host_gray_variant(64) == capi.host_gray_variant()

@@ -30,6 +30,10 @@ def gui_params(image):
     return int(mm_c * 20), mm_c
 
 
+ALLOW_AMBIGUOUS = False      # tools/detect_fuzz.py sets it: an image with a pixel exactly on a histogram edge is flagged, and still checked
+AMBIGUOUS_SEEN = [0]
+
+
 def check_detect(capi, eng, image, mm_r, mm_c, L=10, batch_index=0, res=None):
     d = O.detect_debug(image, mm_r, mm_c, L)
     if res is None:
@@ -40,7 +44,8 @@ def check_detect(capi, eng, image, mm_r, mm_c, L=10, batch_index=0, res=None):
     inf = info[batch_index]
     colour = image.ndim == 3
     assert inf["status"] == 0
-    assert inf["ambiguous"] == 0
+    AMBIGUOUS_SEEN[0] += int(inf["ambiguous"] != 0)
+    assert ALLOW_AMBIGUOUS or inf["ambiguous"] == 0
     thr = capi.host_threshold(inf, colour)
     assert thr == d["threshold"], (thr, d["threshold"])
     mask = eng.debug(batch_index, capi.DBG_MASK, H, W).astype(bool)
@@ -609,6 +614,23 @@ def test_random_small_images_against_oracle(capi, eng, seed):
             check_detect(capi, eng, arr, mm_r, mm_c, L)
         finally:
             eng.set_debug_flags(0)
+
+
+@pytest.mark.parametrize("W", [1, 2, 3])
+def test_colour_images_one_to_three_pixels_wide(capi, eng, W):
+    """numpy evaluates rgb2gray's `rgb @ coeffs` row by row of the image: a dot product for one-pixel-wide images, a
+    matrix-vector product otherwise -- two rounding orders on most hosts (capi.detect_gray_variant(width)).  The binding
+    sets the handle's order from the width of the call's images; found by tools/detect_fuzz.py (seed 408: a 142 x 1 image
+    whose brightest pixel's gray value differs in the last bit between the two orders)."""
+    rng = np.random.default_rng(1408)
+    for _ in range(30):
+        H = int(rng.integers(20, 200))
+        img = rng.integers(0, 90, size=(H, W, 3)).astype(np.uint8)
+        r0 = int(rng.integers(0, H // 2))
+        img[r0:r0 + int(rng.integers(5, H // 2)), :, :] += 150
+        check_detect(capi, eng, np.ascontiguousarray(img), int(rng.integers(0, H)), 0, int(rng.choice([1, 3, 10])))
+    wide = rng.integers(0, 256, size=(64, 80, 3)).astype(np.uint8)      # and back to an ordinary width on the same handle
+    check_detect(capi, eng, wide, 10, 2)
 
 
 def test_uint16_colour_images_detect_profile_and_peaks():

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Extended detect fuzz on the GPU box (minutes of oracle time, not a pytest test): the generator of
+tests/test_gpu_detect.py::test_random_small_images_against_oracle over many more seeds on ONE handle -- what a handle
+learns from one call (class plane, one-pass histogram, window length) steers the next call's path, so a long mixed sequence
+is the test of that state -- and batches of several equally shaped images.  usage: python tools/detect_fuzz.py [seeds] [first]"""
+import importlib.util
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def run(seeds, first):
+    import image_analysis_amd._capi as capi
+    td = _load(os.path.join(ROOT, "tests", "test_gpu_detect.py"), "td")
+    td.ALLOW_AMBIGUOUS = True        # LfaImageInfo.ambiguous != 0 (a pixel within 2^-40 of a histogram edge) is counted, the results still checked
+    eng = capi.Engine(device=0, max_h=256, max_w=256, max_c=3, max_batch=4)
+    t0 = time.time()
+    strips = labels = 0
+    for seed in range(first, first + seeds):
+        try:
+            td.test_random_small_images_against_oracle(capi, eng, seed)
+            rng = np.random.default_rng(5000 + seed)                # a batch of equally shaped images through the same handle
+            n = int(rng.integers(2, 5))
+            kind = int(rng.integers(0, 3))
+            H, W = int(rng.integers(8, 200)), int(rng.integers(8, 200))
+            if rng.random() < 0.5:
+                W = max(16, (W // 16) * 16)
+            top = 255 if kind != 1 else int(rng.choice([255, 4095, 65535]))
+            shape = (n, H, W, 3) if kind == 2 else (n, H, W)
+            batch = rng.integers(0, max(2, top // 3), size=shape).astype(np.int64)
+            for i in range(n):
+                for _b in range(int(rng.integers(0, 5))):
+                    r0, c0 = int(rng.integers(0, H)), int(rng.integers(0, W))
+                    batch[i, r0:r0 + int(rng.integers(1, H)), c0:c0 + int(rng.integers(1, W // 4 + 2))] += int(rng.integers(top // 3, top))
+            batch = np.ascontiguousarray(np.clip(batch, 0, top).astype(np.uint16 if kind == 1 else np.uint8))
+            mm_r, mm_c, L = int(rng.integers(0, H)), int(rng.integers(0, W // 2 + 1)), int(rng.choice([1, 3, 10, 10]))
+            res = eng.detect(batch, mm_r, mm_c, L)
+            for i in range(n):
+                d = td.check_detect(capi, eng, batch[i], mm_r, mm_c, L, batch_index=i, res=res)
+                strips += len(d["strips"]); labels += int(d["n_labels"])
+        except AssertionError:
+            print("MISMATCH at seed", seed, flush=True)
+            raise
+        if seed % 20 == 0:
+            print(f"seed {seed} ok, {time.time() - t0:.0f} s", flush=True)
+    eng.close()
+    print(f"detect fuzz ok: seeds {first}..{first + seeds - 1} ({7 * seeds} calls on one handle; the batches held {labels} labels, {strips} strips; "
+          f"{td.AMBIGUOUS_SEEN[0]} images flagged ambiguous, results equal all the same), {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 12)
