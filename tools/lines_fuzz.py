@@ -27,7 +27,7 @@ def run(cases, seed):
     from oracle import lines_oracle as L
     fz = _load(os.path.join(ROOT, "tests", "test_gpu_fuzz_round2.py"), "fz")
     tl = _load(os.path.join(ROOT, "tests", "test_gpu_lines.py"), "tl")
-    eng = capi.Engine(device=0, max_h=320, max_w=320, max_c=1, max_batch=1)
+    eng = capi.Engine(device=0, max_h=320, max_w=320, max_c=1, max_batch=3)
     eng.set_debug_flags(64)
     rng = np.random.default_rng(seed)
     t0 = time.time()
@@ -72,6 +72,16 @@ def run(cases, seed):
             raise
         eng.set_debug_flags(64)
         boxes += len(d["strips"])
+        if it % 4 == 0:                                             # the same frame beside two variants of it in one call: boxes only
+            batch = np.stack([im, np.ascontiguousarray(im[::-1]), np.ascontiguousarray(im[:, ::-1])])
+            try:
+                want = [L.detect_lines(b) for b in batch]
+            except ValueError:
+                want = None
+            if want is not None:
+                bx, _info = eng.detect_lines(batch)
+                got = [[[int(b["minr"]), int(b["maxr"]), int(b["minc"]), int(b["maxc"])] for b in one] for one in bx]
+                assert got == want, ("batch", it, H, W)
         if it % 25 == 0:
             print(f"case {it}: {H}x{W} ok, {boxes} boxes so far, {time.time() - t0:.0f} s", flush=True)
     print(f"lines fuzz ok: {cases} cases, {refused} refused by the reference as well, {boxes} boxes, {time.time() - t0:.0f} s")
