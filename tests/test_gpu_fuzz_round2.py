@@ -58,13 +58,14 @@ def test_detect_lines_fuzz_on_one_handle_with_growing_frames():
     assert m.run(120, 1) > 20
 
 
-def test_uint16_colour_detect_fuzz():
+def test_uint16_colour_detect_fuzz(seed=77, count=12):
+    """(seed / count: tools/dtype_fuzz.py runs the three generators below over many more seeds)"""
     import image_analysis_amd.detection as detection
     from oracle import lfa_oracle as O
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(seed)
     found = 0
     try:
-        for it in range(12):
+        for it in range(count):
             H, W = int(rng.integers(60, 200)), int(rng.integers(40, 180))
             im = rng.integers(500, 9000, size=(H, W, 3)).astype(np.uint16)
             for _ in range(int(rng.integers(1, 4))):
@@ -80,14 +81,15 @@ def test_uint16_colour_detect_fuzz():
             found += len(want)
     finally:
         detection.min_maxr, detection.min_maxc = 0, 0
-    assert found >= 10
+    assert found >= (10 if seed == 77 else 0)
+    return found
 
 
-def test_region_dtype_fuzz():
+def test_region_dtype_fuzz(seed=5150, count=40):
     import image_analysis_amd.detection as detection
     from oracle import lfa_oracle as O
-    rng = np.random.default_rng(5150)
-    for it in range(40):
+    rng = np.random.default_rng(seed)
+    for it in range(count):
         h, w = int(rng.integers(8, 200)), int(rng.integers(4, 150))
         c = int(rng.choice([0, 3]))
         shape = (h, w, c) if c else (h, w)
@@ -125,22 +127,22 @@ def test_region_dtype_fuzz():
         assert all(np.float64(a).tobytes() == np.float64(b).tobytes() for (_, _, a), (_, _, b) in zip(gk, wk))
 
 
-def test_float64_image_detect_fuzz():
+def test_float64_image_detect_fuzz(seed=4242, count=16):
     """float64 images, 2-D and colour (what rgb2gray / img_as_float hand on): crops against the oracle, including images whose
     corner pixel is foreground (the region test then compares float box means in numpy's summation order)."""
     import image_analysis_amd.detection as detection
     from oracle import lfa_oracle as O
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(seed)
     found = gaps = 0
     try:
-        for it in range(16):
+        for it in range(count):
             H, W = int(rng.integers(60, 200)), int(rng.integers(40, 180))
             colour = bool(it % 2)
             im = rng.random((H, W, 3) if colour else (H, W)) * 0.2 + 0.05
             for _ in range(int(rng.integers(1, 4))):
                 c0 = int(rng.integers(0, W - 8)); w = int(rng.integers(3, 9)); r0 = int(rng.integers(0, H // 2)); h = int(rng.integers(12, H // 2))
                 im[r0:r0 + h, c0:c0 + w] = rng.random(im[r0:r0 + h, c0:c0 + w].shape) * 0.3 + 0.6
-            if it in (5, 6, 9, 10):
+            if it % 16 in (5, 6, 9, 10):
                 im[0:40, 0:6] = 0.9 + rng.random(im[0:40, 0:6].shape) * 0.05      # foreground corner
             if it % 4 == 3:
                 im *= 7.5                                            # values above 1: adjust_gamma's scale stays 1
@@ -159,7 +161,8 @@ def test_float64_image_detect_fuzz():
             detection.detect_lateral_flow_tests(np.zeros((32, 32), np.float32))
     finally:
         detection.min_maxr, detection.min_maxc = 0, 0
-    assert found >= 10 and gaps >= 2
+    assert seed != 4242 or (found >= 10 and gaps >= 2)
+    return found
 
 
 def test_analyze_batch_of_float64_images():
