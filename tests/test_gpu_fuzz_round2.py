@@ -58,7 +58,7 @@ def test_detect_lines_fuzz_on_one_handle_with_growing_frames():
     assert m.run(120, 1) > 20
 
 
-def test_uint16_colour_detect_fuzz(seed=77, count=12):
+def uint16_colour_detect_fuzz(seed=77, count=12):
     """(seed / count: tools/dtype_fuzz.py runs the three generators below over many more seeds)"""
     import image_analysis_amd.detection as detection
     from oracle import lfa_oracle as O
@@ -85,7 +85,7 @@ def test_uint16_colour_detect_fuzz(seed=77, count=12):
     return found
 
 
-def test_region_dtype_fuzz(seed=5150, count=40):
+def region_dtype_fuzz(seed=5150, count=40):
     import image_analysis_amd.detection as detection
     from oracle import lfa_oracle as O
     rng = np.random.default_rng(seed)
@@ -127,7 +127,7 @@ def test_region_dtype_fuzz(seed=5150, count=40):
         assert all(np.float64(a).tobytes() == np.float64(b).tobytes() for (_, _, a), (_, _, b) in zip(gk, wk))
 
 
-def test_float64_image_detect_fuzz(seed=4242, count=16):
+def float64_image_detect_fuzz(seed=4242, count=16):
     """float64 images, 2-D and colour (what rgb2gray / img_as_float hand on): crops against the oracle, including images whose
     corner pixel is foreground (the region test then compares float box means in numpy's summation order)."""
     import image_analysis_amd.detection as detection
@@ -163,6 +163,18 @@ def test_float64_image_detect_fuzz(seed=4242, count=16):
         detection.min_maxr, detection.min_maxc = 0, 0
     assert seed != 4242 or (found >= 10 and gaps >= 2)
     return found
+
+
+def test_uint16_colour_detect_fuzz():
+    uint16_colour_detect_fuzz()
+
+
+def test_region_dtype_fuzz():
+    region_dtype_fuzz()
+
+
+def test_float64_image_detect_fuzz():
+    float64_image_detect_fuzz()
 
 
 def test_analyze_batch_of_float64_images():

@@ -24,9 +24,9 @@ def run(seeds):
         warnings.simplefilter("ignore")
         for seed in range(1, seeds + 1):
             try:
-                a += fz.test_uint16_colour_detect_fuzz(seed, 12)
-                b += fz.test_float64_image_detect_fuzz(seed, 16)
-                fz.test_region_dtype_fuzz(seed, 42)
+                a += fz.uint16_colour_detect_fuzz(seed, 12)
+                b += fz.float64_image_detect_fuzz(seed, 16)
+                fz.region_dtype_fuzz(seed, 42)
             except AssertionError:
                 print("MISMATCH at seed", seed, flush=True)
                 raise
