@@ -374,7 +374,25 @@ __device__ __forceinline__ double rescale_unit(double x, double lo, double hi) {
     return c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
 }
 
+// exclusive prefix of one value per thread over a block of 1024 (16 waves): shuffles inside the wave, the 16 wave totals
+// through LDS; every thread also gets the block's total.  (Two of these replaced two 1024-step loops of thread 0.)
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* s_w, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+    __syncthreads();                                                     // (s_w may still be read from the previous scan)
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const uint32_t w = s_w[k]; all += w; if (k < wv) before += w; }
+    *total = all;
+    return before + inc - v;
+}
+
 __global__ __launch_bounds__(1024) void k_lines_levels(LinesJob j) {
+    __shared__ uint32_t s_w[16];
     __shared__ uint32_t part[1024];
     __shared__ int s_level[4];
     __shared__ double s_p[2];
@@ -385,10 +403,8 @@ __global__ __launch_bounds__(1024) void k_lines_levels(LinesJob j) {
     uint32_t loc[16], a = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { a += gh[t * 16 + k]; loc[k] = a; }
-    part[t] = a;
-    __syncthreads();
-    if (t == 0) { uint32_t s = 0; for (int k = 0; k < 1024; ++k) { const uint32_t v = part[k]; part[k] = s; s += v; } }
-    __syncthreads();
+    uint32_t all_px;
+    part[t] = block_scan_1024(a, s_w, &all_px);
 #pragma unroll
     for (int k = 0; k < 16; ++k) cum[t * 16 + k] = part[t] + loc[k];
     __syncthreads();
@@ -436,11 +452,8 @@ __global__ __launch_bounds__(1024) void k_lines_levels(LinesJob j) {
         loc[k] = f;
         below = v[k];
     }
-    __syncthreads();
-    part[t] = f;
-    __syncthreads();
-    if (t == 0) { uint32_t s = 0; for (int k = 0; k < 1024; ++k) { const uint32_t x = part[k]; part[k] = s; s += x; } }
-    __syncthreads();
+    uint32_t all_cls;
+    part[t] = block_scan_1024(f, s_w, &all_cls);
     int cl[16], first = 16384;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -452,10 +465,10 @@ __global__ __launch_bounds__(1024) void k_lines_levels(LinesJob j) {
     // strictly increasing between their clip points): k_ccl_init then computes min(max(level - a, 0), m) instead of
     // looking the class up.  Checked here entry by entry; where it does not hold (two levels whose floats collide) the
     // table is used.
-    if (t == 0) { s_level[0] = 16384; s_level[1] = (int)(part[1023]); s_level[2] = 1; }
+    __syncthreads();                                                     // (s_level: the percentile search above is done with it)
+    if (t == 0) { s_level[0] = 16384; s_level[1] = (int)all_cls; s_level[2] = 1; }
     __syncthreads();
     if (first < 16384) atomicMin(&s_level[0], first);
-    if (t == 1023) s_level[1] += (int)f;
     __syncthreads();
     const int ca = s_level[0] - 1, cm = s_level[1];
     bool same = true;
