@@ -512,24 +512,30 @@ __global__ __launch_bounds__(256) void k_ccl_init(LinesJob j) {
     // Pixels of one class that sit side by side in a wave's 64 (one row) start out linked to the first of them: the long
     // horizontal runs of a line never form a chain of single links, and k_ccl_merge only joins runs.
     const int lane = threadIdx.x & 63;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;              // (a multiple of 64: a wave's pixels start at a multiple of 64)
-    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < npix; p0 += 4 * stride) {
+    // 32-bit indices (a frame has at most 2^30 pixels, lfa_detect_lines_batch) and the column kept by addition: the only
+    // division is the one that finds the thread's first column -- `p % W` per pixel was most of this kernel's instructions
+    const int np32 = (int)npix, stride = (int)(gridDim.x * blockDim.x);  // (stride: a multiple of 64, so a wave's pixels start at a multiple of 64)
+    const int W = j.W, dx = stride % W;
+    int p0 = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    int x0 = p0 % W;
+    for (; p0 < np32; p0 += 4 * stride) {
         int l[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const int64_t p = p0 + k * stride; l[k] = p < npix ? lv[p] : 0; }
+        for (int k = 0; k < 4; ++k) { const int p = p0 + k * stride; l[k] = p < np32 ? lv[p] : 0; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t p = p0 + k * stride;
-            const bool valid = p < npix;                                 // (a valid lane's lower lanes are valid too)
+            const int p = p0 + k * stride;
+            const bool valid = p < np32;                                 // (a valid lane's lower lanes are valid too)
             const int lev = l[k] & 16383;
             const int c = !valid ? 0 : (cls_fn ? min(max(lev - cls_a, 0), cls_m) : (int)cls[lev]);
-            const int x = (int)((uint32_t)p % (uint32_t)j.W);           // (p < 2^30)
+            const int x = x0;                                            // p % W
+            x0 += dx; if (x0 >= W) x0 -= W;
             const int cleft = __shfl_up(c, 1);
             const unsigned long long starts = __ballot(lane == 0 || x == 0 || c != cleft);
             const int first = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane))));
             if (valid) {
                 cimg[p] = (uint16_t)c;                                   // the class image: what the labelling compares
-                parent[p] = c ? (int)p - (lane - first) : -1;            // background takes no part
+                parent[p] = c ? p - (lane - first) : -1;                 // background takes no part
             }
         }
     }
