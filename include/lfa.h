@@ -156,7 +156,10 @@ int lfa_set_gray_variant(LfaHandle h, int variant);
  * bit3: uint16 images always take the min/max pass before the histogram pass; bit4: never (by default a handle drops the
  * min/max pass once its last completed uint16 call held no value of 16384 or more).
  * bit5: the LDS profile slots of lfa_analyze_batch are sized for the worst case (by default for the longest analysis window
- * of the handle's last completed call; longer windows take the global-memory path). */
+ * of the handle's last completed call; longer windows take the global-memory path).
+ * bit6 (64): lfa_detect_lines_batch keeps the float64 Gaussian image (8 more bytes per pixel) for
+ * lfa_lines_debug_fetch(LFA_LDBG_GAUSS); bit7 (128): its labelling looks every pixel's class up in the class table (by
+ * default the class is computed from the level where the table is "0, then one class per level, then constant"). */
 int lfa_set_debug_flags(LfaHandle h, int flags);
 
 /* ---- detect: detect_lateral_flow_tests(image, line_length) -- detection.py:31-94 ----------------------------------- */
