@@ -2,7 +2,7 @@
 """Extended detect_lines fuzz on the GPU box (not a pytest test: minutes of oracle time): random frames of random shape --
 rows of a multiple of 8 pixels and not, pixel counts that are / are not multiples of 4 and 8 (the 16-byte-load paths of the
 labelling kernels), shapes below one CLAHE tile -- every intermediate (uint16 image, levels, roots) and the boxes against
-oracle/lines_oracle.py.  usage: python tools/lines_fuzz.py [cases] [seed]"""
+oracle/lines_oracle.py.  usage: python tools/lines_fuzz.py [cases] [seed] [largest side]"""
 import importlib.util
 import os
 import sys
@@ -22,18 +22,18 @@ def _load(path, name):
     return m
 
 
-def run(cases, seed):
+def run(cases, seed, top=300):
     import image_analysis_amd._capi as capi
     from oracle import lines_oracle as L
     fz = _load(os.path.join(ROOT, "tests", "test_gpu_fuzz_round2.py"), "fz")
     tl = _load(os.path.join(ROOT, "tests", "test_gpu_lines.py"), "tl")
-    eng = capi.Engine(device=0, max_h=320, max_w=320, max_c=1, max_batch=3)
+    eng = capi.Engine(device=0, max_h=top + 20, max_w=top + 20, max_c=1, max_batch=3)
     eng.set_debug_flags(64)
     rng = np.random.default_rng(seed)
     t0 = time.time()
     refused = boxes = 0
     for it in range(cases):
-        H, W = int(rng.integers(2, 300)), int(rng.integers(2, 300))
+        H, W = int(rng.integers(2, top)), int(rng.integers(2, top))
         if it % 3 == 0:
             W = max(8, W & ~7)
         if it % 5 == 0:
@@ -90,4 +90,5 @@ def run(cases, seed):
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 300, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+        int(sys.argv[3]) if len(sys.argv) > 3 else 300)
