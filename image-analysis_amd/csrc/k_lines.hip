@@ -359,10 +359,12 @@ __global__ __launch_bounds__(256) void k_clahe_blend(LinesJob j, int rows_per_bl
     if ((threadIdx.x & 63) == 0 && hi >= lo) { atomicMin(&j.info[img].cmin, lo); atomicMax(&j.info[img].cmax, hi); }
     __syncthreads();
     uint32_t* gh = j.lhist + (int64_t)img * 16384;
+    // two neighbouring 32-bit bins of the global histogram are one 64-bit word and take one add (the low bin counts pixels of
+    // one frame, < 2^30, so it never carries into the high one)
+    unsigned long long* gh2 = (unsigned long long*)gh;
     for (int k = threadIdx.x; k < 8192; k += 256) {
         const uint32_t w = sh[k];
-        if (w & 0xffffu) atomicAdd(&gh[2 * k], w & 0xffffu);
-        if (w >> 16) atomicAdd(&gh[2 * k + 1], w >> 16);
+        if (w) atomicAdd(&gh2[k], ((unsigned long long)(w >> 16) << 32) | (unsigned long long)(w & 0xffffu));
     }
 }
 
