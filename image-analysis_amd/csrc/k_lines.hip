@@ -663,8 +663,12 @@ __global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
             const int leader = __ffsll((unsigned long long)todo) - 1;
             const int lr = __shfl(r, leader);
             const bool mine = need && r == lr;
-            const int x0 = wave_min_i32(mine ? x : 0x7fffffff);
-            const int y1 = wave_max_i32(mine ? y + 1 : -1), x1 = wave_max_i32(mine ? x + 1 : -1);
+            const unsigned long long mb = __ballot(mine);
+            int x0 = x, y1 = y + 1, x1 = x + 1;                          // the leader's own pixel: all there is when no other lane shares its root
+            if (mb & (mb - 1)) {                                         // (wave-uniform) several lanes: combine them first
+                x0 = wave_min_i32(mine ? x : 0x7fffffff);
+                y1 = wave_max_i32(mine ? y + 1 : -1); x1 = wave_max_i32(mine ? x + 1 : -1);
+            }
             if (lane == leader) {
                 const int yr = (int)((uint32_t)lr / (uint32_t)j.W), xr = (int)((uint32_t)lr - (uint32_t)yr * (uint32_t)j.W);
                 int32_t* e = bbox + 4 * (int64_t)lr;
@@ -673,7 +677,7 @@ __global__ __launch_bounds__(256) void k_ccl_boxes(LinesJob j) {
                 if (x1 - xr > 1) atomicMax(&e[2], x1 - xr);              // maxc - root column
                 cimg[lr] = (uint16_t)0xffff;
             }
-            todo &= ~__ballot(mine);
+            todo &= ~mb;
         }
     };
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
