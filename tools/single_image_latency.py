@@ -1,25 +1,43 @@
 #!/usr/bin/env python3
-"""Latency of the drop-in calls on ONE host image (the GUI's case: one file per click, detection.py:462, :541-543):
-detect_lateral_flow_tests + image_analysis of every strip, host array in, host results out."""
-import importlib, json, os, sys, time
+"""Latency of ONE image through the whole call (the reference GUI's case: one photo, detect + profile + peaks), resident in
+HBM and from host memory, on a warm handle.  usage: python tools/single_image_latency.py"""
+import os
+import sys
+import time
+
+import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-det = importlib.import_module("image_analysis_amd.detection")
-synth = importlib.import_module("image_analysis_amd.synth")
 
-def run(img, name, reps=20):
-    det.min_maxc = int(img.shape[1] / 40); det.min_maxr = det.min_maxc * 20
-    strips = det.detect_lateral_flow_tests(img)                      # warm-up: handle, workspace
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        strips = det.detect_lateral_flow_tests(img)
-    t1 = time.perf_counter()
-    for _ in range(reps):
-        res = [det.image_analysis(s, False) for s in strips]
-    t2 = time.perf_counter()
-    print(json.dumps({"image": name, "strips": len(strips), "detect_ms": round((t1 - t0) / reps * 1e3, 3),
-                      "image_analysis_ms_per_strip": round((t2 - t1) / reps / max(1, len(strips)) * 1e3, 3)}))
 
-run(synth.synth_rgb(1536, 2048, 8, 1234), "1536x2048x3 uint8")
-run(synth.synth_u16(2048, 2048, 40, 1234), "2048x2048 uint16")
-run(synth.synth_rgb(512, 512, 4, 7), "512x512x3 uint8")
+def main():
+    import torch
+    import image_analysis_amd._capi as capi
+    from image_analysis_amd.synth import synth_rgb, synth_u16
+    for name, im in (("1536x2048 RGB uint8", synth_rgb(1536, 2048, 8, 1)), ("2048x2048 uint16", synth_u16(2048, 2048, 40, 2))):
+        H, W = im.shape[:2]
+        Cc = 1 if im.ndim == 2 else 3
+        eng = capi.Engine(device=0, max_h=H, max_w=W, max_c=Cc, max_batch=1)
+        mm_c = int(W / 40); mm_r = mm_c * 20
+        stride = int(H * .6) + 1
+        t = capi.to_device(im[None], eng.device)
+        code = capi.np_dtype_code(im.dtype)
+        for _ in range(5):
+            eng.analyze_raw(t, code, 1, H, W, Cc, mm_r, mm_c, 10, 64, stride)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            eng.analyze_raw(t, code, 1, H, W, Cc, mm_r, mm_c, 10, 64, stride)
+            torch.cuda.synchronize()
+        resident = (time.perf_counter() - t0) / 50
+        t0 = time.perf_counter()
+        for _ in range(20):
+            res, _ = eng.analyze(im[None], mm_r, mm_c)
+        e2e = (time.perf_counter() - t0) / 20
+        print(f"{name}: {resident * 1e3:.3f} ms resident in HBM (call + sync), {e2e * 1e3:.2f} ms from a numpy array to numpy results "
+              f"({len(res[0][0])} strips)", flush=True)
+        eng.close()
+
+
+if __name__ == "__main__":
+    main()
