@@ -24,9 +24,14 @@ Pinning: tests/test_oracle_golden.py checks this file against
   (i)  the known answer the reference's own export holds (images/excel2.xlsx: frame, crop box, profile);
   (ii) vectors produced by executing the reference's numpy-only source lines (detection.py:118-153,
        :205-316) in the build container (tests/golden/make_golden.py; outputs in tests/golden/*.npz).
-The detect path has no reference-run vector beyond (i): the reference needs skimage/cv2/tkinter, which are
-absent here (ordinary ModuleNotFoundError, nothing denied) -- for everything (i) does not cover, detect
-parity is pinned on scipy.ndimage/numpy semantics only.
+tests/test_skimage_vectors.py checks it against
+  (iii) the whole of detect_lateral_flow_tests (detection.py:31-153) executed over the reference's vendored
+       scikit-image 0.20.0 Python sources on 24 small inputs plus the excel2 frame (tests/golden/vendored_skimage.py,
+       make_golden.py; tests/golden/ref_skimage_detect.npz): threshold bits, SHA-256 of gray / gamma / mask / opened mask /
+       label image, the bbox + area table and the returned boxes;
+  (iv) expected values the vendored skimage's own test-suite holds for adjust_gamma, threshold_otsu and rgb2gray.
+Still unpinned: the numpy / scipy underneath are this container's 2.2.6 / 1.15.3, not the reference's 1.24.3 / 1.10.1
+(whose C extensions exist only as darwin-arm64 binaries), and the file decoders (cv2 / tifffile are absent).
 """
 from __future__ import annotations
 

@@ -499,3 +499,75 @@ def test_regions_of_other_dtypes_equal_the_reference_run():
     assert len(kinds) == 6
     with pytest.raises(NotImplementedError):
         detection.image_analysis(np.zeros((40, 20), np.float32), True)
+
+
+def _check_rois_against_oracle(eng, imgs, rois, want_band, rng):
+    """profiles + peaks of `rois` in the order given and shuffled; each ROI's oracle result is computed once."""
+    want = {}
+    for order in (np.arange(len(rois)), rng.permutation(len(rois))):
+        rr = rois[order]
+        eng.timing("*")
+        profs, pk = eng.profiles(imgs, rr, inverse=False, rng=15)
+        kt = eng.timing_read()
+        eng.timing(None)
+        assert ("k_profile_band" in kt) == want_band, sorted(kt)
+        for q, (r, src) in enumerate(zip(rr, order)):
+            if int(src) not in want:
+                want[int(src)] = O.image_analysis(imgs[r["image"], r["r0"]:r["r1"], r["c0"]:r["c1"]], True)
+            wp, wk = want[int(src)]
+            assert profs[q].tobytes() == wp.tobytes(), (q, r)
+            assert pk[q]["n_peaks"] == len(wk), (q, r)
+            for i, (s, e, a) in enumerate(wk):
+                assert (pk[q]["start"][i], pk[q]["end"][i]) == (s, e) and pk[q]["area"][i] == a, (q, r, i)
+
+
+def test_dense_rois_at_the_benchmarked_shape_1536x2048x3():
+    """BASELINE configs[4] at the shape bench.py reports: 1536x2048x3 uint8 images, 256 ROIs per image from synth_rois
+    (h ~ U{64..512}, w ~ U{16..64}).  Rows are 6144 bytes, so k_profile_band runs at its ceiling -- a 4-row band of exactly
+    24 576 bytes, six 16-byte pieces per thread.  ROI array sorted by image -> band kernel; shuffled -> k_profile.  Every
+    profile bit for bit, every peak index and area equal to the oracle (detection.py:205-245 on the slice of :529-533)."""
+    import image_analysis_amd._capi as capi
+    from image_analysis_amd.synth import synth_rgb, synth_rois
+    H, W, n = 1536, 2048, 2
+    imgs = np.stack([synth_rgb(H, W, 8, 1234 + i) for i in range(n)])
+    rois = synth_rois(n, H, W, per_image=256).astype(capi.ROI_DT)
+    assert len(rois) == 512 and (rois["r1"] - rois["r0"]).max() > 480
+    eng = capi.Engine(device=0, max_h=H, max_w=W, max_batch=n)
+    try:
+        _check_rois_against_oracle(eng, imgs, rois, True, np.random.default_rng(3))
+    finally:
+        eng.close()
+
+
+def test_dense_rois_on_2048x2048_uint16_frames():
+    """The same on 16-bit frames: 4096-byte rows, a 4-row band of 16 KiB (8 rows would pass the 24 KiB ceiling)."""
+    import image_analysis_amd._capi as capi
+    from image_analysis_amd.synth import synth_rois, synth_u16
+    H = W = 2048
+    imgs = np.stack([synth_u16(H, W, 40, 1234 + i) for i in range(2)])
+    rois = synth_rois(2, H, W, per_image=160, seed=5).astype(capi.ROI_DT)
+    eng = capi.Engine(device=0, max_h=H, max_w=W, max_batch=2)
+    try:
+        _check_rois_against_oracle(eng, imgs, rois, True, np.random.default_rng(4))
+    finally:
+        eng.close()
+
+
+def test_more_rois_on_one_image_than_a_band_block_lists_at_once():
+    """k_profile_band lists the ROIs of its image 512 at a time (kBandList): one image carrying 1100 ROIs takes three rounds
+    per band block, its neighbour carries 12.  Includes ROIs that end on the image's last row / column."""
+    import image_analysis_amd._capi as capi
+    from image_analysis_amd.synth import synth_rgb, synth_rois
+    H, W = 768, 1024
+    imgs = np.stack([synth_rgb(H, W, 6, 300 + i) for i in range(2)])
+    a = synth_rois(1, H, W, per_image=1100, seed=11).astype(capi.ROI_DT)
+    b = synth_rois(1, H, W, per_image=12, seed=12).astype(capi.ROI_DT)
+    b["image"] = 1
+    a[3] = (0, H - 70, H, W - 20, W)                         # bottom-right corner of the image
+    a[700] = (0, 0, 64, 0, 16)                               # top-left corner
+    rois = np.concatenate([a, b])
+    eng = capi.Engine(device=0, max_h=H, max_w=W, max_batch=2)
+    try:
+        _check_rois_against_oracle(eng, imgs, rois, True, np.random.default_rng(5))
+    finally:
+        eng.close()
