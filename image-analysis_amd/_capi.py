@@ -61,6 +61,7 @@ def _load():
     lib.lfa_set_gamma_lut.argtypes = [vp, i32, vp, i32]
     lib.lfa_set_gray_variant.argtypes = [vp, i32]
     lib.lfa_set_debug_flags.argtypes = [vp, i32]
+    lib.lfa_set_host_pow.argtypes = [vp, vp, i32]
     lib.lfa_set_debug_flags.restype = i32
     lib.lfa_detect_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp]
     lib.lfa_profile_batch.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp, vp]
@@ -85,7 +86,7 @@ def _load():
     for name in ("lfa_timing_enable", "lfa_timing_read","lfa_create", "lfa_destroy", "lfa_set_gamma_lut", "lfa_set_gray_variant", "lfa_detect_batch",
                  "lfa_profile_batch", "lfa_profile_lut_batch", "lfa_peaks_batch", "lfa_analyze_batch", "lfa_gaussian_batch",
                  "lfa_debug_fetch", "lfa_sync", "lfa_stream_wait_passes", "lfa_chain_passes", "lfa_analyze_batch_static", "lfa_reserve",
-                 "lfa_detect_lines_batch", "lfa_lines_debug_fetch", "lfa_profile_any_batch"):
+                 "lfa_detect_lines_batch", "lfa_lines_debug_fetch", "lfa_profile_any_batch", "lfa_set_host_pow"):
         getattr(lib, name).restype = i32
     return lib
 
@@ -98,7 +99,7 @@ EXPORTED = ("lfa_version", "lfa_last_error", "lfa_create", "lfa_destroy", "lfa_s
             "lfa_gaussian_batch", "lfa_debug_fetch", "lfa_sync", "lfa_timing_enable", "lfa_timing_read",
             "lfa_stream_wait_passes", "lfa_chain_passes", "lfa_analyze_batch_static", "lfa_static_workspace_bytes", "lfa_reserve",
             "lfa_workspace_bytes", "lfa_detect_lines_batch", "lfa_lines_debug_fetch",
-            "lfa_profile_any_batch")
+            "lfa_profile_any_batch", "lfa_set_host_pow")
 
 
 def _check(rc):
@@ -257,6 +258,54 @@ def host_threshold(info_row, colour: bool):
     return float((edges[k] + edges[k + 1]) / 2.0)
 
 
+HOST_POW_DOUBLES = 2 + 257 + 256          # include/lfa.h LfaHostPow
+
+
+def _first_gray_with(gmin, gmax, targets, strict, gamma):
+    """Per target t: the smallest float64 g in [gmin, gmax] with g ** gamma >= t (strict: > t), by bisection over the bit
+    patterns of the doubles (non-negative doubles are ordered like their int64 patterns) with THIS host's numpy power --
+    the function the reference applies to every pixel (skimage/exposure/exposure.py:679).  +inf where gmax ** gamma
+    does not reach the target, gmin where gmin ** gamma already does."""
+    targets = np.asarray(targets, dtype=np.float64)
+
+    def pred(bits):
+        v = bits.view(np.float64) ** gamma
+        return (v > targets) if strict else (v >= targets)
+
+    lo = np.full(targets.shape, np.float64(gmin).view(np.int64), dtype=np.int64)
+    hi = np.full(targets.shape, np.float64(gmax).view(np.int64), dtype=np.int64)
+    none, at_min = ~pred(hi), pred(lo)
+    while True:
+        gap = hi - lo
+        if not (gap > 1).any():
+            break
+        mid = lo + (gap >> 1)
+        p = pred(mid)
+        hi = np.where(p, mid, hi)
+        lo = np.where(p, lo, mid)
+    return np.where(none, np.inf, np.where(at_min, np.float64(gmin), hi.view(np.float64)))
+
+
+def host_pow_tables(gmin, gmax, gamma=0.4):
+    """One LfaHostPow record (include/lfa.h) for an image whose gray values span [gmin, gmax], every pow() evaluated by this
+    host's numpy exactly as the reference evaluates it: vmin / vmax (exposure.py:679), the 257 histogram edges of
+    threshold_otsu's 256-bin float histogram (np.linspace between them; exposure.py:298-301, numpy/lib/histograms.py:800-859)
+    mapped back to gray space, and per Otsu bin the gray-space form of `gamma_image > bin centre` (thresholding.py:378-381,
+    detection.py:47)."""
+    v = np.array([gmin, gmax], dtype=np.float64) ** gamma
+    out = np.empty(HOST_POW_DOUBLES, dtype=np.float64)
+    out[0], out[1] = v[0], v[1]
+    if v[0] == v[1]:
+        out[2:] = np.inf
+        out[2] = gmin
+        return out
+    edges = np.linspace(v[0], v[1], 257)
+    centres = (edges[:-1] + edges[1:]) / 2.0
+    out[2:259] = _first_gray_with(gmin, gmax, edges, False, gamma)
+    out[259:] = _first_gray_with(gmin, gmax, centres, True, gamma)
+    return out
+
+
 class Engine:
     """One LfaHandle on one device.  Not thread-safe (like the reference's module globals)."""
 
@@ -351,8 +400,30 @@ class Engine:
             raise ValueError("expected a batch (n,H,W) or (n,H,W,3)")
         return images, n, H, W, Cc, np_dtype_code(images.dtype)
 
-    def detect(self, images: np.ndarray, min_maxr, min_maxc, line_length=10, max_strips=64):
-        """Batch detect.  Returns (list of STRIP_DT arrays, INFO_DT array)."""
+    # -- images the device flagged `ambiguous`: decided again with the host's pow (lfa_set_host_pow) -------------------------
+    @staticmethod
+    def _ambiguous(inf):
+        """indices of the images of an INFO_DT array that need the host-pow run"""
+        return np.flatnonzero((inf["ambiguous"] != 0) & ((inf["status"] & 4) == 0))
+
+    def _gather_images(self, images_t, dtype_code, H, W, Cc, idx):
+        """the images `idx` of a resident batch as a contiguous batch of their own"""
+        torch = _torch()
+        ib = H * W * Cc * {LFA_U8: 1, LFA_U16: 2, LFA_F64: 8}[dtype_code]
+        flat = images_t.reshape(-1).view(torch.uint8)
+        rows = flat[: (flat.numel() // ib) * ib].reshape(-1, ib)
+        return rows[torch.as_tensor(np.asarray(idx, dtype=np.int64), device=flat.device)].contiguous()
+
+    def _set_host_pow(self, inf_rows):
+        tab = np.stack([host_pow_tables(float(r["gmin"]), float(r["gmax"])) for r in inf_rows])
+        self._host_pow_t = to_device(tab, self.device)     # kept alive until the next call has run
+        _check(lib.lfa_set_host_pow(self._h, self._host_pow_t.data_ptr(), len(inf_rows)))
+
+    def detect(self, images: np.ndarray, min_maxr, min_maxc, line_length=10, max_strips=64, resolve_ambiguous=True):
+        """Batch detect.  Returns (list of STRIP_DT arrays, INFO_DT array).  Images whose LfaImageInfo.ambiguous is non-zero
+        (a pixel within 2^-40 of a histogram edge or of the threshold: only there could the device's pow() and the host's
+        disagree) are run a second time with tables built by the host's numpy (host_pow_tables); their info rows then have
+        status bit 2 set."""
         images, n, H, W, Cc, code = self._prep(images)
         out_s, out_i = [], []
         for b0 in range(0, n, self.max_batch):
@@ -367,12 +438,34 @@ class Engine:
                     ms = min(1024, ms * 4)
                     continue
                 break
-            if (inf["status"] != 0).any():
+            if (inf["status"] & 3).any():
                 raise LfaError(-3, f"detect overflow (status {inf['status'].tolist()}): more than 1024 strips per image")
-            cn = from_device(counts, np.int32, b1 - b0)
-            st = from_device(strips, STRIP_DT, (b1 - b0) * ms).reshape(b1 - b0, ms)
-            out_s += [st[i, :cn[i]].copy() for i in range(b1 - b0)]
-            out_i.append(inf.copy())
+            cn = from_device(counts, np.int32, b1 - b0).copy()
+            st = from_device(strips, STRIP_DT, (b1 - b0) * ms).reshape(b1 - b0, ms).copy()
+            inf = inf.copy()
+            rows = [st[i, :cn[i]].copy() for i in range(b1 - b0)]
+            amb = self._ambiguous(inf) if resolve_ambiguous else []
+            if len(amb):
+                # pixels within 2^-40 of a histogram edge or of the threshold: those images again, with the host's pow()
+                sub = self._gather_images(t, code, H, W, Cc, amb)
+                ms2 = ms
+                while True:
+                    self._set_host_pow(inf[amb])
+                    s2, c2, i2 = self.detect_raw(sub, code, len(amb), H, W, Cc, int(min_maxr), int(min_maxc), int(line_length), ms2)
+                    i2 = from_device(i2, INFO_DT, len(amb)).copy()
+                    if (i2["status"] & 1).any() and ms2 < 1024:
+                        ms2 = min(1024, ms2 * 4)
+                        continue
+                    break
+                if (i2["status"] & 3).any() or ((i2["status"] & 4) == 0).any():
+                    raise LfaError(-3, f"the host-pow run of an ambiguous image did not go through (status {i2['status'].tolist()})")
+                c2 = from_device(c2, np.int32, len(amb))
+                s2 = from_device(s2, STRIP_DT, len(amb) * ms2).reshape(len(amb), ms2)
+                for k, i in enumerate(amb):
+                    rows[int(i)] = s2[k, :c2[k]].copy()
+                inf[amb] = i2
+            out_s += rows
+            out_i.append(inf)
         return out_s, np.concatenate(out_i)
 
     @staticmethod
@@ -380,7 +473,7 @@ class Engine:
         """Host arrays of one analyze_raw call -> (per image (strips, [profile...], peaks), INFO_DT array); None for the first
         element when an image overflowed max_strips (status bit 0: the caller re-runs with more)."""
         inf = info[: n * INFO_DT.itemsize].view(INFO_DT)
-        if (inf["status"] & ~1).any():
+        if (inf["status"] & 2).any():
             raise LfaError(-3, f"analyze overflow (status {inf['status'].tolist()}): run capacity exceeded")
         if (inf["status"] & 1).any():
             return None, inf
@@ -394,19 +487,43 @@ class Engine:
             res.append((st[i, :k].copy(), [pr[i, q, :pk[i, q]["length"]].copy() for q in range(k)], pk[i, :k].copy()))
         return res, inf
 
-    def analyze_device(self, images_t, dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length, max_strips, stride):
+    def analyze_device(self, images_t, dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length, max_strips, stride,
+                       resolve_ambiguous=True, host_pow_rows=None):
         """analyze_raw on a resident batch + the same ladder as `detect`: an image with more accepted regions than
-        max_strips (status bit 0) sends the batch round again with 4x the slots, up to the ABI's 1024."""
+        max_strips (status bit 0) sends the batch round again with 4x the slots, up to the ABI's 1024; images flagged
+        `ambiguous` go round again with the host's pow() tables (see `detect`).  host_pow_rows: INFO_DT rows (gmin, gmax) of
+        the n images -- every run of the ladder then uses tables built from them (lfa_set_host_pow)."""
         ms = int(max_strips)
         while True:
+            if host_pow_rows is not None:
+                self._set_host_pow(host_pow_rows)
             out = self.analyze_raw(images_t, dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length, ms, stride)
             strips, counts, info, _rois, profiles, peaks = [t.cpu().numpy() for t in out]
             res, inf = self.unpack_analysis(n, ms, stride, strips, counts, info, profiles, peaks)
             if res is not None:
-                return res, inf.copy()
+                inf = inf.copy()
+                if resolve_ambiguous and host_pow_rows is None:
+                    return self.resolve_ambiguous(images_t, dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length, ms, stride, res, inf)
+                return res, inf
             if ms >= 1024:
                 raise LfaError(-3, f"analyze overflow (status {inf['status'].tolist()}): more than 1024 strips per image")
             ms = min(1024, ms * 4)
+
+    def resolve_ambiguous(self, images_t, dtype_code, n, H, W, Cc, min_maxr, min_maxc, line_length, max_strips, stride, res, inf):
+        """(res, inf) of an analyze call with the images flagged `ambiguous` replaced by their host-pow run."""
+        amb = self._ambiguous(inf)
+        if not len(amb):
+            return res, inf
+        sub = self._gather_images(images_t, dtype_code, H, W, Cc, amb)
+        r2, i2 = self.analyze_device(sub, dtype_code, len(amb), H, W, Cc, min_maxr, min_maxc, line_length, max_strips, stride,
+                                     host_pow_rows=inf[amb].copy())
+        if ((i2["status"] & 4) == 0).any():
+            raise LfaError(-3, "the host-pow run of an ambiguous image did not go through")
+        res = list(res)
+        for k, i in enumerate(amb):
+            res[int(i)] = r2[k]
+        inf[amb] = i2
+        return res, inf
 
     def analyze(self, images: np.ndarray, min_maxr, min_maxc, line_length=10, max_strips=64):
         """detect + image_analysis(strip, False) per strip.  Returns per image: (strips, [profile...], PEAKS_DT array)."""
@@ -605,6 +722,13 @@ class Engine:
         _check(lib.lfa_debug_fetch(self._h, image_index, DBG_TABLE, out.data_ptr(), max(k, 1) * 20,
                                    current_stream_ptr(self.device)))
         return out.cpu().numpy().reshape(-1, 5)[:k]
+
+    def debug_hist(self, image_index, nbins=256):
+        """Histogram counts of image `image_index` of the last call (LFA_DBG_HIST): 256 bins for colour / uint8 images."""
+        torch = _torch()
+        out = torch.zeros(nbins, dtype=torch.int32, device=self.device)
+        _check(lib.lfa_debug_fetch(self._h, image_index, DBG_HIST, out.data_ptr(), nbins * 4, current_stream_ptr(self.device)))
+        return out.cpu().numpy().view(np.uint32)
 
     def debug_used_plane(self, image_index):
         """True if the mask of image `image_index` of the last call was decided from the class plane (LFA_DBG_PLANE)."""

@@ -151,20 +151,26 @@ __global__ __launch_bounds__(256) void k_edges_rgb(Job j) {
     const int img = blockIdx.x;
     LfaImageInfo* inf = &j.info[img];
     const double gmin = inf->gmin, gmax = inf->gmax;
-    const double vmin = gamma_pow(gmin), vmax = gamma_pow(gmax);
+    // lfa_set_host_pow: vmin, vmax and the gray-space edges come from the caller's record -- no pow() is evaluated here
+    const double* hp = j.host_pow ? j.host_pow + (int64_t)img * kHostPowDoubles : nullptr;
+    const double vmin = hp ? hp[0] : gamma_pow(gmin), vmax = hp ? hp[1] : gamma_pow(gmax);
     uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
-    if (threadIdx.x == 0) { inf->vmin = vmin; inf->vmax = vmax; inf->all_equal = (vmin == vmax) ? 1 : 0; }
+    if (threadIdx.x == 0) { inf->vmin = vmin; inf->vmax = vmax; inf->all_equal = (vmin == vmax) ? 1 : 0; if (hp) inf->status |= 4; }
     bool anycrit = false;
     for (int i = threadIdx.x; i < kEdges; i += 256) {
         bool crit = false;
         double* t = j.edges_g + (int64_t)img * kEdges;
         double ti;
-        if (vmin == vmax) {
+        if (hp) {
+            ti = hp[2 + i];
+        } else if (vmin == vmax) {
             ti = (i == 0) ? gmin : __longlong_as_double(0x7ff0000000000000LL);
         } else {
             const Linspace lin(vmin, vmax, kEdges);
             const double e = lin(i);
             ti = first_true(gmin, gmax, pow(e, 2.5), [e](double g) { return gamma_pow(g) >= e; });
+            if ((j.debug_flags & (256 | 512)) && i >= 1 && i <= 255 && ti < 1.0e300 && ti > 0.0)   // test hook: as if pow() differed in its last bit
+                ti = __longlong_as_double(__double_as_longlong(ti) + ((j.debug_flags & 256) ? 1 : -1));
         }
         t[i] = ti;
         eg[i] = (i == 0) ? 0u : g_threshold(ti, &crit);       // edge 0 (= gmin) is below every pixel
@@ -796,7 +802,8 @@ __global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
     const double centre = ctr[best];
     inf->otsu_bin = best; inf->v_thr_f = centre;
     // mask = pow(gray, 0.4) > centre  <=>  gray >= T  with T the first double whose power exceeds the centre
-    const double T = first_true(inf->gmin, inf->gmax, pow(centre, 2.5), [centre](double g) { return gamma_pow(g) > centre; });
+    const double T = j.host_pow ? j.host_pow[(int64_t)img * kHostPowDoubles + 2 + kEdges + best]
+                                : first_true(inf->gmin, inf->gmax, pow(centre, 2.5), [centre](double g) { return gamma_pow(g) > centre; });
     const long long tb = __double_as_longlong(T);
     inf->g_thr = (tb > 0 && tb < 0x7ff0000000000000LL) ? __longlong_as_double(tb - 1) : T;
     // integer form of `gray >= T` for k_mask (critical -> k_mask takes the float64 path)

@@ -161,6 +161,8 @@ struct LfaContext {
     bool u16_have_pred = false, u16_plane_on = true, pending_had_pred = false;
     int u16_thr_mean = 0, u16_thr_spread = 0;   // mean and (largest - smallest) threshold of that call
     int win_hint = 0;                      // longest analysis window of the last completed call (rows), 0 = unknown
+    const double* host_pow = nullptr;      // lfa_set_host_pow: records for the next detect / analyze call (device memory), used once
+    int host_pow_n = 0;
     // detect_lines workspace (lfa_detect_lines_batch), allocated by the first call that needs it
     bool ln_bbox_dirty = false;
     Buf ln_g, ln_u, ln_binlut, ln_maps, ln_levels, ln_lhist, ln_lval, ln_cls, ln_clsfn, ln_cimg, ln_parent, ln_bbox, ln_cand, ln_info;
@@ -366,8 +368,14 @@ size_t carve_workspace(Workspace& w, unsigned char* base, size_t capacity, int n
 int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int W, int C, int min_maxr, int min_maxc,
                 int L, LfaStrip* out_strips, int max_strips, int32_t* out_counts, LfaImageInfo* out_info,
                 LfaRoi* out_rois, hipStream_t s, lfa::Job* job_out, bool static_ws = false, LfaRoi** ws_rois = nullptr, bool allow_f64 = false) {
+    // tables of lfa_set_host_pow are for this call and no other, whether it goes through or not
+    const double* host_pow = h ? h->host_pow : nullptr;
+    const int host_pow_n = h ? h->host_pow_n : 0;
+    if (h) { h->host_pow = nullptr; h->host_pow_n = 0; }
     int rc = check_images(h, images, dtype, n, H, W, C, allow_f64);
     if (rc) return rc;
+    if (host_pow && host_pow_n != n)
+        return fail(LFA_ERR_ARG, "lfa_set_host_pow gave %d record(s), this call has %d image(s); the tables are withdrawn", host_pow_n, n);
     if (H > 65535 || W > 65535) return fail(LFA_ERR_ARG, "image sides above 65535 are not supported");
     if ((long long)H * W > (1ll << 30)) return fail(LFA_ERR_UNSUPPORTED, "images above 2^30 pixels are not supported");
     if (n > 65535 || (H + 7) / 8 > 65535) return fail(LFA_ERR_UNSUPPORTED, "more than 65535 frames per call, or frames taller than 524280 rows, are not supported");
@@ -415,6 +423,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         if (h->have_done && s != h->last_stream) LFA_HIP(hipStreamWaitEvent(s, h->done_event, 0));
         if (ws_rois) *ws_rois = (LfaRoi*)h->ws.rois.p;
     }
+    j.host_pow = (C == 3 || dtype == LFA_F64) ? host_pow : nullptr;
     if (!out_rois && ws_rois) out_rois = *ws_rois;          // lfa_analyze_batch without a caller's ROI buffer
     lfa::OutPtrs o{out_strips, out_counts, out_info, out_rois};
     TimerScope ts(static_ws ? nullptr : h);
@@ -534,6 +543,16 @@ int lfa_set_gray_variant(LfaHandle h, int variant) {
     if (!h) return fail(LFA_ERR_ARG, "null handle");
     if (variant < 0 || variant >= LFA_GRAY_NVARIANTS) return fail(LFA_ERR_ARG, "gray variant %d not in [0,%d)", variant, LFA_GRAY_NVARIANTS);
     h->gray_variant = variant;
+    return LFA_OK;
+}
+
+int lfa_set_host_pow(LfaHandle h, const LfaHostPow* tables, int n) {
+    if (!h) return fail(LFA_ERR_ARG, "null handle");
+    static_assert(sizeof(LfaHostPow) == lfa::kHostPowDoubles * 8, "LfaHostPow layout");
+    if (!tables) { h->host_pow = nullptr; h->host_pow_n = 0; return LFA_OK; }
+    if (n < 1 || n > h->max_batch) return fail(LFA_ERR_ARG, "n=%d outside [1, max_batch=%d]", n, h->max_batch);
+    if ((uintptr_t)tables & 7) return fail(LFA_ERR_ARG, "tables must be 8-byte aligned");
+    h->host_pow = (const double*)tables; h->host_pow_n = n;
     return LFA_OK;
 }
 

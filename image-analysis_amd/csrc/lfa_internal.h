@@ -19,6 +19,7 @@ constexpr int kEdgesI_MaskCrit = 259;    // != 0: mask threshold critical -> flo
 constexpr int kEdgesI_Bins = 260;        // != 0: the image's class plane (Job::bins) is valid and k_mask may use it
 constexpr int kEdgesI_Class = 261;       // uint16 class plane: the class q of the image's threshold x_thr; bit 8: x_thr is the last value
                                          // of class q, so that class is clear as a whole and k_mask never looks at the frame (k_otsu_int)
+constexpr int kHostPowDoubles = 2 + 257 + 256;   // sizeof(LfaHostPow) / 8
 constexpr int kStatsWords = 12;          // Job::plane_stats
 constexpr int kAreaMin = 100;            // detection.py:81
 constexpr int kMaxCand = 1 << 20;
@@ -87,6 +88,7 @@ struct Job {
     uint32_t* rowsum;        // [n][rowsum_cap] integer row sums of analysis windows (written by k_box_sums)
     int32_t rowsum_cap;      // 16 * H
     int32_t* slot_rs_off;    // [n][max_strips] the same offset per output strip slot (written by k_finalize)
+    const double* host_pow;  // [n] LfaHostPow records (lfa_set_host_pow) or null: vmin, vmax, 257 gray-space edges, 256 gray-space thresholds
     const uint8_t* lut8;     // [256]
     const uint16_t* lut16;   // [65536]
 };

@@ -122,6 +122,11 @@ def analyze_stream(frames, batch=16, device=0, line_length=10, max_strips=64, mi
             with torch.cuda.stream(comp_s):
                 per_image, _inf = eng.analyze_device(slot["dev"], code, n, H, W, Cc, mm_r, mm_c, int(line_length),
                                                      min(1024, max_strips * 4), stride)
+        elif len(eng._ambiguous(_inf)):
+            # a pixel within 2^-40 of a histogram edge: those frames again with the host's pow() (Engine.detect)
+            with torch.cuda.stream(comp_s):
+                per_image, _inf = eng.resolve_ambiguous(slot["dev"], code, n, H, W, Cc, mm_r, mm_c, int(line_length), max_strips,
+                                                        stride, per_image, _inf.copy())
         res = [(index0 + i, *per_image[i]) for i in range(n)]
         slot["busy"] = False
         slot["out"] = slot["host_out"] = None

@@ -105,8 +105,10 @@ typedef struct {
     int32_t n_candidates;     /* labels with area >= 100 */
     int32_t n_accepted;       /* after the mean test and check_duplicate (detection.py:81-85) */
     int32_t n_strips;         /* after remove_outliers (detection.py:87); may exceed max_strips -> see status */
-    int32_t status;           /* 0 ok; bit0: n_strips/n_accepted exceeded max_strips (outputs truncated);
-                                 bit1: run capacity exceeded */
+    int32_t status;           /* bit0: n_strips/n_accepted exceeded max_strips (outputs truncated);
+                                 bit1: run capacity exceeded;
+                                 bit2 (informational, not an error): the image was decided from the caller's host-pow
+                                 tables (lfa_set_host_pow) */
 } LfaImageInfo;
 
 /* ---- lifetime ---------------------------------------------------------------------------------------------------- */
@@ -143,6 +145,27 @@ int lfa_set_gamma_lut(LfaHandle h, int dtype, const void* lut, int n);
  * value is read when a call is made; calls already enqueued keep theirs. */
 int lfa_set_gray_variant(LfaHandle h, int variant);
 
+/* Colour / float64 images whose LfaImageInfo.ambiguous came back non-zero: decide them again with the HOST's pow().
+ * The reference bins pow(gray, 0.4) with its host's libm / numpy (skimage/exposure/exposure.py:679,
+ * numpy/lib/histograms.py:800-859, skimage/filters/thresholding.py:364-381); the device evaluates the 257 histogram edges and
+ * the threshold with ITS pow() and counts in `ambiguous` the pixels within 2^-40 (relative) of one of them -- the only
+ * pixels another pow() could put on the other side.  For such an image the caller builds one LfaHostPow from the image's
+ * gmin / gmax with the host's pow (the Python binding: _capi.host_pow_tables, numpy) and runs the image again:
+ *   tables: DEVICE memory, n records; they are used by the handle's NEXT detect / analyze call (plain or static), which must
+ *   pass exactly n images (else LFA_ERR_ARG), and by that call only; the memory must stay valid until that call's kernels
+ *   have run.  NULL (with any n) withdraws tables not yet used.
+ * In that call the device evaluates no pow() at all: vmin / vmax, the gray-space edges and the gray-space threshold of
+ * every Otsu bin come from the record, everything else (min/max, histogram, Otsu scan, mask, ...) runs as always, and
+ * LfaImageInfo.status has bit2 set.  2-D integer images ignore the tables (their path has no pow()). */
+typedef struct {
+    double vmin, vmax;        /* pow(gmin, 0.4), pow(gmax, 0.4) */
+    double edges_g[257];      /* edges_g[i] = smallest double g in [gmin, gmax] with pow(g, 0.4) >= linspace(vmin, vmax, 257)[i];
+                                 +inf where no such g exists; vmin == vmax: edges_g[0] = gmin, the rest +inf */
+    double thr_g[256];        /* thr_g[b] = smallest double g in [gmin, gmax] with pow(g, 0.4) > (edge[b] + edge[b+1]) / 2 in
+                                 gamma space, +inf where none: the mask of an image whose Otsu bin is b is gray >= thr_g[b] */
+} LfaHostPow;
+int lfa_set_host_pow(LfaHandle h, const LfaHostPow* tables, int n);
+
 /* Test hook (no counterpart in the reference).  bit0: colour images take the float64 compare path even when the exact
  * integer form of the thresholds is available (that path otherwise runs only for "critical" thresholds).
  * bit1: images do not use the per-pixel class plane between the histogram and the mask pass (the mask pass then
@@ -159,7 +182,10 @@ int lfa_set_gray_variant(LfaHandle h, int variant);
  * of the handle's last completed call; longer windows take the global-memory path).
  * bit6 (64): lfa_detect_lines_batch keeps the float64 Gaussian image (8 more bytes per pixel) for
  * lfa_lines_debug_fetch(LFA_LDBG_GAUSS); bit7 (128): its labelling looks every pixel's class up in the class table (by
- * default the class is computed from the level where the table is "0, then one class per level, then constant"). */
+ * default the class is computed from the level where the table is "0, then one class per level, then constant").
+ * bit8 (256) / bit9 (512): k_edges_rgb moves every interior gray-space histogram edge it computed one double up / down --
+ * what a pow() whose last bit differs would do -- so that the tests can show an image with a pixel exactly on an edge
+ * going wrong without lfa_set_host_pow and right with it (tables from lfa_set_host_pow are never touched). */
 int lfa_set_debug_flags(LfaHandle h, int flags);
 
 /* ---- detect: detect_lateral_flow_tests(image, line_length) -- detection.py:31-94 ----------------------------------- */
