@@ -850,6 +850,19 @@ static int blocks_per_image(const Job& j, int px_per_block) {
         default: LFA_LAUNCH(#KERNEL, KERNEL<5>, GRID, BLOCK, 0, STREAM, JOB); break;             \
     }
 
+// blocks of k_hist_rgb the chip holds at once.  Queried once per process -- by lfa_create, so that no detect / analyze
+// call makes a runtime query (a call may be under stream capture: lfa_analyze_batch_static).
+int hist_rgb_capacity() {
+    static const int capacity = [] {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_hist_rgb<0>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1024;
+        return per_cu * prop.multiProcessorCount;
+    }();
+    return capacity;
+}
+
 hipError_t launch_threshold(const Job& j, hipStream_t s) {
     LFA_LAUNCH("k_init_info", k_init_info, dim3(j.H >= 4096 ? 8 : 2, j.n), dim3(256), 0, s, j);
     if (j.wait_event) {                                   // lfa_chain_passes: the passes below start when the other handle's are done
@@ -864,13 +877,7 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
         {
             // the histogram blocks live for the whole launch (grid-stride), so the grid is sized to whole rounds of
             // what the chip holds at once: 4096 blocks on a capacity of 1280 would run 3.2 rounds, i.e. pay for 4
-            static const int capacity = [] {
-                int per_cu = 0, dev = 0;
-                hipDeviceProp_t prop;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_hist_rgb<0>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-                if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1024;
-                return per_cu * prop.multiProcessorCount;
-            }();
+            const int capacity = hist_rgb_capacity();
             int per_image = (3 * capacity + j.n / 2) / j.n;
             const int need = (int)(((int64_t)j.H * j.W + 256 * 64 - 1) / (256 * 64));
             if (per_image > need) per_image = need;

@@ -390,7 +390,8 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     // that pipeline use several handles (bench.py, frames.analyze_stream), and the device still has the other handles' calls
     // queued while this one waits.  LFA_POLL_COUNTERS=1 restores the non-blocking look (hipEventQuery) for comparison.
     static const bool poll = [] { const char* e = getenv("LFA_POLL_COUNTERS"); return e && *e == '1'; }();
-    if (h->plane_pending && (poll ? hipEventQuery(h->plane_event) == hipSuccess : hipEventSynchronize(h->plane_event) == hipSuccess)) {
+    // (not in a static call: it takes fixed paths, and a host wait would not be legal under stream capture)
+    if (!static_ws && h->plane_pending && (poll ? hipEventQuery(h->plane_event) == hipSuccess : hipEventSynchronize(h->plane_event) == hipSuccess)) {
         h->plane_pending = false;
         if (h->plane_host[1]) h->plane_on = 2u * h->plane_host[0] >= h->plane_host[1];
         if (h->plane_host[3]) { h->u16_max = (int)h->plane_host[2]; h->u16_one_pass = h->plane_host[2] < (uint32_t)lfa::kLdsBinsU16; }
@@ -412,11 +413,15 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
                         "the static workspace holds LFA_STATIC_SCRATCH_BYTES = %zu; pass fewer or smaller images, or use lfa_analyze_batch",
                         n, H, W, C, L, max_strips, need, (size_t)LFA_STATIC_SCRATCH_BYTES);
         j = make_job(h, w, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
+        // no events either: nothing is recorded for, or awaited from, other handles (lfa_stream_wait_passes /
+        // lfa_chain_passes do not see static calls), so the call is kernels and memsets on `s` only and can be captured
+        j.passes_event = nullptr; j.wait_event = nullptr;
         j.plane_stats = nullptr; j.bins = nullptr; j.u16_plane = 0; j.hist_abs = 0; j.win_hint = 0;
         j.u16_lds_bins = lfa::kLdsBinsU16; j.u16_pred = 0; j.u16_pa = 0; j.u16_ps = 0;
         if (ws_rois) *ws_rois = (LfaRoi*)w.rois.p;
     } else {
         // (after the counters: the workspace depends on the paths they select)
+        h->have_last = false;                        // lfa_debug_fetch must not follow pointers a failed call may have freed
         if ((rc = ensure_workspace(h, n, H, W, C, dtype, L, max_strips))) return rc;
         j = make_job(h, h->ws, images, dtype, n, H, W, C, min_maxr, min_maxc, L, max_strips);
         // the handle's workspace is shared by its calls: a call on another stream than the last one waits for that one
@@ -479,6 +484,7 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         lfa_destroy(h);
         return fail(LFA_ERR_HIP, "uploading gamma tables failed");
     }
+    (void)lfa::hist_rgb_capacity();                                               // the one runtime query of the launchers, made here
     if ((rc = static_scratch_lookup(device))) { lfa_destroy(h); return rc; }      // set-up of lfa_analyze_batch_static, once per device
     // the whole workspace for calls within the handle's limits at the defaults (line_length >= 10, max_strips <= 64), class
     // plane and big-image Otsu buffers included; lfa_reserve widens those two limits
@@ -774,6 +780,7 @@ int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, in
     j.w0 = w3[1]; j.w1 = w3[0];
     const size_t N = (size_t)n, npix = (size_t)H * W;
     const bool keep_gauss = (h->debug_flags & 64) != 0;                           // lfa_lines_debug_fetch(LFA_LDBG_GAUSS) needs it
+    h->have_lines = false;                                                        // lfa_lines_debug_fetch must not follow pointers a failed call may have freed
     if ((keep_gauss && (rc = ensure(h->ln_g, N * npix * 8))) || (rc = ensure(h->ln_u, N * npix * 2)) || (rc = ensure(h->ln_binlut, N * 65536)) ||
         (rc = ensure(h->ln_maps, N * (size_t)j.nty * j.ntx * 256 * 4)) || (rc = ensure(h->ln_levels, N * npix * 2)) ||
         (rc = ensure(h->ln_lhist, N * 16384 * 4)) || (rc = ensure(h->ln_lval, N * 16384 * 8)) || (rc = ensure(h->ln_cls, N * 16384 * 2)) || (rc = ensure(h->ln_clsfn, N * 16)) || (rc = ensure(h->ln_cimg, N * npix * 2)) ||

@@ -271,7 +271,10 @@ int lfa_analyze_batch(LfaHandle h, const void* images, int dtype, int n, int H, 
  * file-scope device array of LFA_STATIC_SCRATCH_BYTES inside the library (each GPU the library runs on holds its own copy
  * until the process ends; its address is looked up once per device in lfa_create), and the call makes no hipMalloc /
  * hipFree / allocating library call, does no kernel timing and feeds nothing back to the handle's path choices (it always
- * takes the plane-less, min/max-first paths, whose results are identical to the others').
+ * takes the plane-less, min/max-first paths, whose results are identical to the others').  It consists of kernel launches
+ * and hipMemsetAsync on `stream` and nothing else -- no host wait (not even for the previous call's counters), no event
+ * recorded or awaited: lfa_stream_wait_passes / lfa_chain_passes do not see static calls, and the call can be captured
+ * into a HIP graph and replayed (tests/test_zz_no_alloc.py does that under hipStreamCaptureModeGlobal).
  *   - a batch whose workspace does not fit fails with LFA_ERR_ARG and a message naming the bytes needed; at the default
  *     line_length 10 and max_strips 64 the array holds e.g. 4 images of 1536x2048x3, 3 frames of 2048x2048 uint16 or one
  *     image of 3072x4096x3;
