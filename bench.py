@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--free-running", action="store_true", help="after the timed region, time the same steps again with no ordering between the lanes (reported as `free_running`); off by default so that a profile of the default command holds one schedule only")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary configurations (the `configs` object)")
     ap.add_argument("--config-steps", type=int, default=10, help="timed steps of each secondary configuration")
+    ap.add_argument("--config-batch", type=int, default=128, help="N > 1: images per GPU of configs[3] (3072x4096x3)")
+    ap.add_argument("--config-chunk", type=int, default=64, help="N > 1: images per call of configs[3]")
     return ap.parse_args()
 
 
@@ -311,7 +313,8 @@ def main():
     # ---- N > 1: configs[3] (the configuration BASELINE.json names for the scaling curve) on every rank, with its own gather
     if world > 1 and not args.no_configs:
         bc = importlib.import_module("benchmarks_configs")
-        r = bc.bench_big(steps=args.config_steps, seed0=77 + 4 * rank, keep_pipeline=True, barrier=barrier)
+        r = bc.bench_big(B=args.config_batch, CH=min(args.config_chunk, args.config_batch), pool=min(4, args.config_batch),
+                         steps=args.config_steps, seed0=77 + 4 * rank, keep_pipeline=True, barrier=barrier)
         pl = r.pop("_pipeline")
         dt3 = max_over_ranks(r["ms_per_step"] * 1e-3)
         s3 = sum_over_ranks(r["strips_per_step"])
@@ -336,11 +339,14 @@ def main():
             # algorithmic bytes of one launch = what the stage must read + what it must write, once each:
             # the three image passes of the colour front end; every other kernel is priced at the image bytes (a lower bound
             # on nothing: they are latency-bound and never dominant)
+            # SURVEY.md 8(d) prices S1+S2 (gray / gamma / histogram) at N*C*s bytes READ: that is `frac`.  What the kernel
+            # additionally writes by this implementation's own choice (k_hist_rgb: the 4-bit class plane, N/2 bytes) is
+            # reported beside it as `frac_with_plane_store`, never inside `frac`.
             npx = H * W
             per_image = {"k_minmax_rgb": npx * 3,                 # image in
-                         "k_hist_rgb": npx * 3 + npx // 2,         # image in, class plane out (4 bits per pixel)
-                         "k_front_rgb": npx * 3 + npx // 2,
+                         "k_hist_rgb": npx * 3,                    # image in
                          "k_mask": npx // 2 + npx // 8}.get(dominant, img_bytes)   # class plane in, bit mask out
+            own_store = {"k_hist_rgb": npx // 2}.get(dominant, 0)  # class plane out (4 bits per pixel)
             alg_bytes = CH * per_image
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             traffic, traffic_source = None, None
@@ -354,6 +360,7 @@ def main():
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
+                    "frac_with_plane_store": round((alg_bytes + CH * own_store) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "note": (f"timed region: {NS} lanes, the image passes of consecutive chunks chained (lfa_chain_passes), so a launch of "
                              "this kernel has the chip to itself but for the tail kernels of the chunks before; "
                              if NS > 1 and args.stagger == 2 else

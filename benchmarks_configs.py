@@ -64,8 +64,12 @@ def _kernel_table(kt, top=8):
 class _Pipeline:
     """B resident images in chunks of CH alternating over NS handles / streams through lfa_analyze_batch, like bench.py."""
 
-    def __init__(self, batch, code, B, CH, H, W, Cc, mm_r, mm_c, ms, NS=2):
+    def __init__(self, batch, code, B, CH, H, W, Cc, mm_r, mm_c, ms, NS=None):
         dev = DEV()
+        # bench.py's schedule: three lanes, the image passes of consecutive chunks chained (lfa_chain_passes), their tails
+        # beside the next chunk's passes.  LFA_STREAMS / LFA_CHAIN=0 (lanes run free) / LFA_STAGGER=1 for comparisons.
+        NS = NS or int(os.environ.get("LFA_STREAMS", "3"))
+        NS = max(1, min(NS, (B + CH - 1) // CH))
         self.batch, self.code, self.B, self.CH, self.H, self.W, self.Cc = batch, code, B, CH, H, W, Cc
         self.mm_r, self.mm_c, self.ms, self.NS = mm_r, mm_c, ms, NS
         self.stride = int(H * .6) + 1
@@ -76,12 +80,18 @@ class _Pipeline:
         self.info = capi.dev_bytes(B * 104, dev); self.rois = capi.dev_bytes(B * ms * 20, dev)
         self.prof = torch.empty(B * ms * self.stride, dtype=torch.float64, device=dev); self.peaks = capi.dev_bytes(B * ms * 40, dev)
         self.stagger = int(os.environ.get("LFA_STAGGER", "0"))
+        self.chain = NS > 1 and not self.stagger and os.environ.get("LFA_CHAIN", "1") == "1"
+        if self.chain:
+            for i in range(NS):
+                capi._check(capi.lib.lfa_chain_passes(self.engs[i]._h, self.engs[i - 1]._h))
+        self.turn = 0                    # chunks take the lanes in turn across steps too
         torch.cuda.synchronize()
 
     def step(self, ns=None):
         ns = ns or self.NS
         ms, st = self.ms, self.stride
-        for ci, b0 in enumerate(range(0, self.B, self.CH)):
+        for b0 in range(0, self.B, self.CH):
+            ci, self.turn = self.turn, self.turn + 1
             nb = min(self.CH, self.B - b0)
             stream = C.c_void_p(self.streams[ci % ns].cuda_stream)
             if self.stagger and ns > 1:          # this chunk's passes start when the previous chunk's histogram pass is done
@@ -105,6 +115,8 @@ class _Pipeline:
 
     def close(self):
         for e in self.engs:
+            capi._check(capi.lib.lfa_chain_passes(e._h, None))
+        for e in self.engs:
             e.close()
 
 
@@ -112,7 +124,9 @@ def _front_end_bytes(CH, H, W, Cc, code):
     """algorithmic bytes per launch of the whole-image kernels, for `dominant`"""
     npx = H * W
     s = Cc * (2 if code == capi.LFA_U16 else 1)
-    table = {"k_minmax_rgb": npx * 3, "k_hist_rgb": npx * 3 + npx // 2, "k_minmax_u16": npx * 2, "k_hist_u16": npx * 2 + npx // 2,
+    # SURVEY.md 8(d): S1+S2 are priced at the image bytes READ; the class plane the histogram kernels also write (N/2 bytes, this
+    # implementation's own choice) is not counted
+    table = {"k_minmax_rgb": npx * 3, "k_hist_rgb": npx * 3, "k_minmax_u16": npx * 2, "k_hist_u16": npx * 2,
              "k_hist_u8": npx, "k_mask": npx // 2 + npx // 8}
     return lambda k: CH * table.get(k, npx * s)
 
@@ -129,14 +143,14 @@ def bench_u16(B=1024, CH=256, pool=8, real=False, steps=10):
         pool_np = np.stack([synth.synth_u16(H, W, 40, 1234 + i) for i in range(pool)])
     p = torch.from_numpy(pool_np.view(np.uint8).reshape(pool, -1)).to(DEV())
     batch = p[torch.arange(B, device=DEV()) % pool].contiguous()
-    pl = _Pipeline(batch, capi.LFA_U16, B, CH, H, W, 1, 1020, 51, 64, NS=int(os.environ.get("LFA_STREAMS", "2")))
+    pl = _Pipeline(batch, capi.LFA_U16, B, CH, H, W, 1, 1020, 51, 64)
     for _ in range(3):                  # the handles settle their choices (one-pass histogram, class plane, LDS slots)
         pl.step(); torch.cuda.synchronize()
     dt = timed(pl.step, steps)
     kt = pl.kernel_times()
     ns, inf = pl.results()
     out = {"config": f"{B} resident copies of the reference's 12-bit frame excel2 (2048x2048 uint16), rolled per pool slot" if real else f"configs[2]: {B} resident 2048x2048 uint16 frames (pool of {pool} synthetic frames, 40 strips each, replicated)",
-           "frames": B, "chunk": CH, "streams": pl.NS, "pool": pool, "steps": steps, "ms_per_step": round(dt * 1e3, 3),
+           "frames": B, "chunk": CH, "streams": pl.NS, "chained": bool(pl.chain), "pool": pool, "steps": steps, "ms_per_step": round(dt * 1e3, 3),
            "frames_per_s": round(B / dt, 1), "strips_per_s": round(ns / dt, 1), "labels_mean": float(inf["n_labels"].mean()),
            "runs_mean": float(inf["n_runs"].mean()), "algorithmic_bytes_per_step": B * pl.ib,
            "e2e_frac_hbm": round(B / dt * pl.ib / (HBM_PEAK_GBS * 1e9), 4),
@@ -158,7 +172,7 @@ def bench_big(B=128, CH=64, pool=4, steps=10, seed0=77, keep_pipeline=False, bar
     kt = pl.kernel_times()
     ns, inf = pl.results()
     out = {"config": f"configs[3]: 3072x4096 RGB uint8 images, synthetic, 8 strips each ({B} resident per GPU from a pool of {pool}, cycled)",
-           "images": B, "chunk": CH, "pool": pool, "steps": steps, "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(B / dt, 1),
+           "images": B, "chunk": CH, "streams": pl.NS, "chained": bool(pl.chain), "pool": pool, "steps": steps, "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(B / dt, 1),
            "strips_per_s": round(ns / dt, 1), "strips_per_step": ns, "ambiguous": int(inf["ambiguous"].sum()),
            "algorithmic_bytes_per_step": B * pl.ib, "e2e_frac_hbm": round(B / dt * pl.ib / (HBM_PEAK_GBS * 1e9), 4),
            "dominant": dominant(kt, _front_end_bytes(CH, H, W, 3, capi.LFA_U8)), "kernel_ms_one_stream": _kernel_table(kt)}

@@ -39,10 +39,17 @@ def test_two_ranks_started_by_bench_itself_rehearsal_on_one_gpu():
     env = dict(os.environ, LFA_BENCH_REHEARSAL="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, env=env, capture_output=True, text=True, timeout=900)
+    # without --no-configs: the N > 1 branch also runs configs[3] (3072x4096x3 images) on every rank with its own record
+    # gather -- the code the driver's 8-GPU run goes through -- here with 4 images per rank and one timed step
+    small = [a for a in SMALL if a != "--no-configs"] + ["--config-batch", "4", "--config-chunk", "2", "--config-steps", "1"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                  # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["gather"]["records"] == d["strips_per_step"] > 0 and d["gather"]["backend"].startswith("gloo")
+    c3 = d["configs"]["configs[3]"]
+    assert c3["n_gpus"] == 2 and c3["images"] == 4 and c3["scaling"] == "weak"
+    assert c3["gather"]["records"] == c3["strips_per_step"] == 2 * 4 * 8 and c3["gather"]["backend"].startswith("gloo")
+    assert c3["images_per_s"] > 0 and 0 < c3["e2e_frac_hbm"] < 1
