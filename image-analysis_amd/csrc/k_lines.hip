@@ -10,13 +10,15 @@
 //                                                   :248-280, map_histogram :305-310 ; img_as_uint SP/skimage/util/dtype.py
 //   np.percentile (80, 99), method 'linear'         numpy lib/_function_base_impl.py _quantile / _lerp
 //   rescale_intensity(in_range=(p80, p99), (0, 1))  SP/skimage/exposure/exposure.py:577-589
-//   label of a non-boolean image                    SP/skimage/measure/_label.py:30-120 (equal values, 8-connected, 0 = background,
-//                                                   numbered in raster order of the first pixel)
+//   label of a non-boolean image                    SP/skimage/measure/_label.py:30-120 -> _ccomp.label_cython on an np.intp copy of
+//                                                   the image (equal INTEGER values, 8-connected, 0 = background, numbered in
+//                                                   raster order of the first pixel): of a float image in [0, 1] only the
+//                                                   pixels equal to 1.0 are foreground, as one class
 //   regionprops .bbox + the area / shape filter     detection.py:187-200
 // After CLAHE the image holds at most 16384 distinct values (the uint16 `levels`), and everything downstream is a
 // monotone function of the level: percentiles come from the level histogram, the float the reference would hold for a
-// level is computed once per level (`lval`), and "equal float values" becomes "equal class" with one class per distinct
-// value of lval (class 0 = value 0 = background).  Components are labelled on the class image with a pixel union-find
+// level is computed once per level (`lval`), and "equal integer values" becomes "equal class" with class = (intp) lval
+// (0 = background below 1.0, 1 at 1.0).  Components are labelled on the class image with a pixel union-find
 // whose roots are the smallest pixel index, i.e. the raster-first pixel the reference numbers its labels by.
 // -ffp-contract=off (the build's flag): every float operation below is the single IEEE operation numpy performs.
 #include "lfa_internal.h"
@@ -440,32 +442,24 @@ __global__ __launch_bounds__(1024) void k_lines_levels(LinesJob j) {
     __syncthreads();
     const double p80 = s_p[0], p99 = s_p[1];
     if (t == 0) { inf->p80 = p80; inf->p99 = p99; }
-    // value the reference holds for each level after both rescales; a new class wherever it differs from the level below
+    // value the reference holds for each level after both rescales, and its class: label() of a non-boolean image works on
+    // an np.intp copy of it (skimage/measure/_ccomp: typed buffer of DTYPE = intp), so a float in [0, 1] is truncated -- 0
+    // (background) below 1.0, class 1 at exactly 1.0, i.e. at and above the 99th percentile
     double* lval = j.lval + (int64_t)img * 16384;
     uint16_t* cls = j.cls + (int64_t)img * 16384;
-    uint32_t f = 0;
-    double v[16];
-    double below = (t == 0) ? 0.0 : rescale_unit(rescale_unit((double)(t * 16 - 1), cmin, cmax), p80, p99);
+    int cl[16], first = 16384, top = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        v[k] = rescale_unit(rescale_unit((double)(t * 16 + k), cmin, cmax), p80, p99);
-        lval[t * 16 + k] = v[k];
-        if (v[k] != below) ++f;                                          // (level 0 against 0.0: background stays class 0)
-        loc[k] = f;
-        below = v[k];
-    }
-    uint32_t all_cls;
-    part[t] = block_scan_1024(f, s_w, &all_cls);
-    int cl[16], first = 16384;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        cl[k] = (v[k] == 0.0) ? 0 : (int)(part[t] + loc[k]);
+        const double v = rescale_unit(rescale_unit((double)(t * 16 + k), cmin, cmax), p80, p99);
+        lval[t * 16 + k] = v;
+        cl[k] = (v >= 1.0) ? (int)(long long)v : 0;                       // (both rescales end in [0, 1]; NaN -> 0 like the cast of a NaN here)
         cls[t * 16 + k] = (uint16_t)cl[k];
         if (cl[k] > 0 && first == 16384) first = t * 16 + k;
+        top = max(top, cl[k]);
     }
-    // The table is almost always "0 up to a level a, then one new class per level, then constant" (both rescales are
-    // strictly increasing between their clip points): k_ccl_init then computes min(max(level - a, 0), m) instead of
-    // looking the class up.  Checked here entry by entry; where it does not hold (two levels whose floats collide) the
+    const uint32_t all_cls = (uint32_t)__syncthreads_or(top);             // 0 or 1
+    // The table is "0 up to a level a, then 1" (both rescales are non-decreasing): k_ccl_init then computes
+    // min(max(level - a, 0), m) instead of looking the class up.  Checked here entry by entry; where it does not hold the
     // table is used.
     __syncthreads();                                                     // (s_level: the percentile search above is done with it)
     if (t == 0) { s_level[0] = 16384; s_level[1] = (int)all_cls; s_level[2] = 1; }

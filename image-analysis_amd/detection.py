@@ -97,7 +97,8 @@ def remove_outliers(lst):
 def detect_lines(image) -> list:
     """detection.py:156-201 -> [[minr, maxr, minc, maxc], ...] (the reference defines this function and never calls it).
 
-    Gaussian, local threshold, gamma 0.5, CLAHE, percentile rescale, labelling of equal values and the box filter all run
+    Gaussian, local threshold, gamma 0.5, CLAHE, percentile rescale, labelling (of the image cast to intp, as skimage's
+    label does: the pixels at 1.0) and the box filter all run
     on the device (`lfa_detect_lines_batch`); the matplotlib figure of :162-164 is not drawn.  Like the reference it needs
     a 2-D image: on colour input the reference fails at `minr, minc, maxr, maxc = region.bbox` (:189)."""
     image = np.asanyarray(image)

@@ -319,10 +319,15 @@ typedef struct {
 /* = for image in batch: detect_lines(image) for 2-D uint8 / uint16 images (C == 1; the reference's function fails on
  *   colour input at its `minr, minc, maxr, maxc = region.bbox`).  Stages: gaussian(sigma 1) -> threshold_local(block 3,
  *   'gaussian') -> image * (threshold > 0) -> adjust_gamma(0.5) -> equalize_adapthist(clip_limit 0.05) -> percentile
- *   rescale (80, 99) -> label (equal values, 8-connected) -> bounding boxes -> area / shape filter, all on the device.
+ *   rescale (80, 99) -> label (skimage labels an np.intp copy of a non-boolean image: of this float image in [0, 1] the
+ *   pixels equal to 1.0, 8-connected) -> bounding boxes -> area / shape filter, all on the device.
  * w_sigma1: HOST, 9 taps of scipy's Gaussian kernel for sigma 1; w_local: HOST, 3 taps for sigma (3-1)/6; NULL = computed
  *   here with the C library's exp().
  * out_boxes: device, n*max_boxes, in the order the reference appends them; out_counts: device, n; out_info: device, n, or NULL.
+ *   Cost of max_boxes: the boxes that pass the filter (at most max_boxes are kept) are ranked by one 256-thread block per image
+ *   with an O(m^2) compare loop -- nothing for the handful a real frame yields, 4e9 compares at the limit of 65536; the dense
+ *   ROI path likewise indexes its ROI array with one block (k_roi_index, linear in n_rois).  Keep max_boxes near what the
+ *   frames can yield (the Python binding starts at 256 and grows on overflow).
  * The workspace of this path (about 26 bytes per pixel) is allocated by the first call that needs it and grows with later
  * ones: unlike detect/analyze, this call MAY allocate (and then waits for the device). */
 int lfa_detect_lines_batch(LfaHandle h, const void* images, int dtype, int n, int H, int W,

@@ -23,6 +23,14 @@ darwin-arm64 binary only): its rule -- neighbours (8-connected in 2-D) with EQUA
 background, labels number the components in raster order of their first pixel -- is restated in `label_equal` and pinned by
 the known-answer arrays the vendored test-suite holds (SP/skimage/measure/tests/test_ccomp.py:14-24, :58-62, :76-99), not by
 a run of the reference on full frames: "parity unpinned" for that one step beyond those vectors.
+
+The image detect_lines hands to label() is FLOAT64 in [0, 1].  `_ccomp.label_cython` keeps its data in a typed buffer
+`cnp.ndarray[DTYPE_t]` with DTYPE = np.intp (the binary holds the names DTYPE, intp, array, order and the message "Buffer
+dtype mismatch"; `_label.py:40-51` documents "ndarray of dtype int"), so the image is converted to intp first: every value
+below 1.0 becomes background 0 and only the pixels whose rescaled value is exactly 1.0 -- at or above the 99th percentile --
+are foreground, all of one class.  `label_as_skimage` restates that (round 3; before, every distinct float level was taken
+as a class of its own, which no integer vector of the vendored suite could tell apart from the truncating rule).  The
+conversion itself cannot be run here (darwin binary): it stays "parity unpinned".
 """
 from __future__ import annotations
 
@@ -186,6 +194,13 @@ def label_equal(values: np.ndarray) -> np.ndarray:
     return out.reshape(H, W)
 
 
+def label_as_skimage(values: np.ndarray) -> np.ndarray:
+    """skimage.measure.label(values) for any non-boolean dtype: `_ccomp.label_cython` works on an intp copy of the image
+    (typed buffer `cnp.ndarray[DTYPE_t]`, DTYPE = np.intp), i.e. floats are truncated toward zero before neighbours are
+    compared.  On detect_lines' image in [0, 1]: foreground = the pixels equal to 1.0."""
+    return label_equal(np.array(values, dtype=np.intp))
+
+
 def lines_debug(image: np.ndarray) -> dict:
     """Every intermediate of detect_lines (detection.py:156-201) for a 2-D image."""
     image = np.asanyarray(image)
@@ -203,7 +218,7 @@ def lines_debug(image: np.ndarray) -> dict:
     e = rescale_unit(lv.astype(np.float64), lv.min(), lv.max())             # _adapthist.py:88-89
     p80, p99 = np.percentile(e, (80, 99))
     e2 = rescale_unit(e, p80, p99)
-    lab = label_equal(e2)
+    lab = label_as_skimage(e2)
     strips = []
     objs = ndi.find_objects(lab)
     boxes = np.zeros((len(objs), 4), np.int64)
