@@ -430,8 +430,11 @@ __device__ __noinline__ void peaks_search_global(const double* p, int len, int i
 
 // analyze_peaks / the two-peak logic on profiles in global memory: G lanes per profile, profiles staged in LDS.
 // Lengths come from `lengths` (lfa_peaks_batch) or from the ROI list the profiles were computed for (rois != null).
+#ifndef LFA_PEAKS_WPE
+#define LFA_PEAKS_WPE 4
+#endif
 template <int G>
-__global__ __launch_bounds__(256) void k_peaks(const double* profiles, const int32_t* lengths, int n, int stride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LFA_PEAKS_WPE))) void k_peaks(const double* profiles, const int32_t* lengths, int n, int stride,
                                                int inverse, int window, int two, int rng, LfaPeaks* out, int lstride,
                                                Job j, const LfaRoi* rois, const int32_t* counts, int slots,
                                                const int32_t* roi_lut, int n_luts) {
@@ -469,20 +472,24 @@ __global__ __launch_bounds__(256) void k_peaks(const double* profiles, const int
     else peaks_search_global<G>(g, len, inverse, window, two, rng, lg == 0 ? &out[i] : nullptr);
 }
 
-// LDS plan: `lstride` float64 slots per profile.  Prefer 16 lanes per profile (4 per wave) with as many waves per block as
-// 64 KiB allow; fall back to one wave per profile, then to no LDS staging at all.
+// LDS plan: `lstride` float64 slots per profile, ONE wave per block (round 3: blocks of four waves ended with their slowest
+// profile and the kernel ran in two uneven rounds -- 0.116 -> 0.099 ms for the 16 384 profiles of configs[4]'s 64-image call).
+// 16 lanes per profile (four per wave) while the slots are short; 32 lanes once a slot passes 2.5 KiB -- the search is a
+// chain of dependent steps whose length hardly depends on the group width, so wider groups cost nothing per profile and
+// halve what a wave keeps in LDS (0.099 -> 0.076 ms at 512-row slots; at 288 rows 16 lanes are 10 % faster); one wave per
+// profile when even two do not fit 64 KiB, no LDS staging at all beyond that.  (More waves per SIMD through a register cap,
+// amdgpu_waves_per_eu 5 / 6 / 8: 0.075 / 0.085 / 0.090 ms -- it is not occupancy that bounds the kernel.)
 struct LdsPlan { int g, threads, lstride; size_t bytes; };
 
 static LdsPlan plan_lds(int max_len) {
     LdsPlan p;
     const int ls = (max_len + 1) & ~1;
     const size_t per = (size_t)ls * 8;
-    if (per * 4 <= 65536) {                         // one wave of four 16-lane groups fits
-        int waves = 4;
-        while (waves > 1 && per * 4 * waves > 65536) waves >>= 1;
-        p.g = 16; p.threads = 64 * waves; p.lstride = ls; p.bytes = per * 4 * waves;
-    } else if (per <= 65536) {
-        p.g = 64; p.threads = 64; p.lstride = ls; p.bytes = per;
+    static const int env_g = [] { const char* e = getenv("LFA_PEAKS_G"); return e ? atoi(e) : 0; }();      // experiments only
+    int g = per <= 2560 ? 16 : (per * 2 <= 65536 ? 32 : 64);
+    if ((env_g == 8 || env_g == 16 || env_g == 32 || env_g == 64) && per * (64 / env_g) <= 65536) g = env_g;
+    if (per * (64 / g) <= 65536) {
+        p.g = g; p.threads = 64; p.lstride = ls; p.bytes = per * (64 / g);
     } else {
         p.g = 64; p.threads = 256; p.lstride = 0; p.bytes = 0;
     }
@@ -497,6 +504,12 @@ static void launch_peaks_k(const double* profiles, const int32_t* lengths, int n
     const dim3 grid((n + ppb - 1) / ppb), block(p.threads);
     if (p.g == 16)
         LFA_LAUNCH("k_peaks", k_peaks<16>, grid, block, p.bytes, s, profiles, lengths, n, stride, inverse, window, two, rng, out,
+                   p.lstride, j, rois, counts, slots, roi_lut, n_luts);
+    else if (p.g == 32)
+        LFA_LAUNCH("k_peaks", k_peaks<32>, grid, block, p.bytes, s, profiles, lengths, n, stride, inverse, window, two, rng, out,
+                   p.lstride, j, rois, counts, slots, roi_lut, n_luts);
+    else if (p.g == 8)
+        LFA_LAUNCH("k_peaks", k_peaks<8>, grid, block, p.bytes, s, profiles, lengths, n, stride, inverse, window, two, rng, out,
                    p.lstride, j, rois, counts, slots, roi_lut, n_luts);
     else
         LFA_LAUNCH("k_peaks", k_peaks<64>, grid, block, p.bytes, s, profiles, lengths, n, stride, inverse, window, two, rng, out,

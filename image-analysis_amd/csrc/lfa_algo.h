@@ -47,10 +47,19 @@ LFA_HD double np_pairwise_leaf(const F& f, int off, int n) {       // n <= 128
     return res;
 }
 
-// The recursion of numpy's pairwise sum (split at n/2 rounded down to a multiple of 8 until a piece has <= 128
-// elements) written with an explicit stack, so that the device code has no recursive call (no scratch stack frames).
-// The big-n part is rare (profiles, windows and peaks are short) and kept out of line on the device, so that its stack
-// arrays and registers do not weigh on the kernels that inline np_pairwise.
+// The recursion of numpy's pairwise sum (split at n/2 rounded down to a multiple of 8 until a piece has <= 128 elements;
+// result = sum(left) + sum(right)) as a post-order walk over the leaves, left to right, WITHOUT a stack in memory: the only
+// state per level is the finished sum of a left child that waits for its right sibling (`acc`, kept in registers -- it
+// is only ever indexed by unrolled compile-time constants, the level wanted is picked by compares) and one bit that says
+// whether the walk is in the left or the right child there (`path`); the (offset, length) of a node is recomputed by
+// descending from the root along those bits.  (Rounds 1-2 kept four 28-entry stack arrays: 576 bytes of scratch memory
+// per lane for every kernel that inlines np_pairwise, and a scratch access per step.)
+// kPwDepth levels cover n <= 128 * 2^(kPwDepth-1) elements and more (pieces are at most n/2 + 8 long): 1 M elements.
+constexpr int kPwDepth = 14;
+constexpr int kPwMaxN = 1 << 20;
+
+LFA_HD int np_pairwise_split(int n) { int n2 = n / 2; return n2 - (n2 % 8); }
+
 struct SeqLeaf {
     template <class F>
     LFA_HD double operator()(const F& f, int off, int n) const { return np_pairwise_leaf(f, off, n); }
@@ -58,28 +67,37 @@ struct SeqLeaf {
 
 template <class F, class LEAF>
 LFA_HD_NOINLINE double np_pairwise_big(const F& f, int off, int n, const LEAF& leaf) {
-    int f_off[28], f_n[28], f_stage[28];
-    double f_left[28];
-    int sp = 0;
-    f_off[0] = off; f_n[0] = n; f_stage[0] = 0; f_left[0] = 0.0;
-    double ret = 0.0;
-    while (sp >= 0) {
-        const int cn = f_n[sp], co = f_off[sp];
-        if (cn <= 128) { ret = leaf(f, co, cn); --sp; continue; }
-        int n2 = cn / 2;
-        n2 -= n2 % 8;
-        if (f_stage[sp] == 0) {
-            f_stage[sp] = 1;
-            ++sp; f_off[sp] = co; f_n[sp] = n2; f_stage[sp] = 0;
-        } else if (f_stage[sp] == 1) {
-            f_left[sp] = ret; f_stage[sp] = 2;
-            ++sp; f_off[sp] = co + n2; f_n[sp] = cn - n2; f_stage[sp] = 0;
-        } else {
-            ret = f_left[sp] + ret;
-            --sp;
+    double acc[kPwDepth];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 0; k < kPwDepth; ++k) acc[k] = 0.0;
+    unsigned path = 0;                       // bit d: at depth d the walk is in the right child
+    int depth = 0, o = off, m = n;
+    for (;;) {
+        while (m > 128 && depth < kPwDepth) { m = np_pairwise_split(m); ++depth; }     // down the left spine (bits stay 0)
+        double r = leaf(f, o, m);
+        while (depth > 0 && ((path >> (depth - 1)) & 1u)) {                            // a right child is done: left + right
+            double l = 0.0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int k = 0; k < kPwDepth; ++k) l = (k == depth - 1) ? acc[k] : l;
+            r = l + r;
+            --depth;
+        }
+        if (depth == 0) return r;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int k = 0; k < kPwDepth; ++k) acc[k] = (k == depth - 1) ? r : acc[k];     // a left child is done: park it,
+        path = (path & ((1u << (depth - 1)) - 1u)) | (1u << (depth - 1));              // go to its right sibling
+        o = off; m = n;
+        for (int d = 0; d < depth; ++d) {
+            const int n2 = np_pairwise_split(m);
+            if ((path >> d) & 1u) { o += n2; m -= n2; } else { m = n2; }
         }
     }
-    return ret;
 }
 
 template <class F>
