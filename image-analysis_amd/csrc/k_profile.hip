@@ -11,6 +11,17 @@
 #include "lfa_algo.h"
 #include "lfa_device.h"
 
+#ifdef LFA_PEAKS_CLOCK
+__device__ unsigned long long lfa_ck[16 * 1024];
+extern "C" int lfa_debug_clocks(unsigned long long* out16) {       // dev aid: read and clear the phase clocks
+    static unsigned long long h[16 * 1024];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(lfa_ck), sizeof h) != hipSuccess) return -1;
+    for (int k = 0; k < 16; ++k) { out16[k] = 0; for (int b = 0; b < 1024; ++b) out16[k] += h[k * 1024 + b]; }
+    for (auto& v : h) v = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(lfa_ck), h, sizeof h) == hipSuccess ? 0 : -1;
+}
+#endif
+
 namespace lfa {
 
 // np.argmax / np.argmin over p[0..n): first extremum, first NaN wins.  Called by the G lanes of one group (G = 16 or 64
@@ -33,32 +44,40 @@ struct GroupWalk {
     }
 };
 
+// np.argmax / np.argmin over p[0..n): first extremum, first NaN wins.  Every lane scans the elements lg, lg + G, lg + 2G, ...
+// -- eight LDS reads requested before the first compare, the compares written as selects (round 3: one read per iteration,
+// each waited for, and a branch per condition made the three searches of a profile the largest part of the kernel) -- and
+// keeps (value, index, is-NaN) of its first extremum; a NaN, once met, stays.  Then over the group: the extreme value
+// (group_ext_f64), and the smallest index among the lanes that hold it (group_min_i32); if any lane met a NaN, the smallest
+// index among those instead.  Two reductions on the DPP path in place of log2(G) rounds of four ds_bpermute and a compare tree.
 template <int G>
 struct GroupArgExt {
     __device__ __forceinline__ int operator()(const double* p, int n, bool want_min) const {
         const int lg = threadIdx.x & (G - 1);
-        double m = 0.0; int idx = 0x7fffffff; bool isn = false;
-        for (int i = lg; i < n; i += G) {
-            const double x = p[i];
-            if (idx == 0x7fffffff) { m = x; idx = i; isn = (x != x); if (isn) break; continue; }
-            const bool upd = want_min ? !(x >= m) : !(x <= m);
-            if (upd) { m = x; idx = i; if (x != x) { isn = true; break; } }
-        }
+        constexpr int kNone = 0x7fffffff;
+        double m = 0.0; int idx = kNone; int isn = 0;
+        constexpr int U = 8;
+        for (int i0 = lg; i0 < n; i0 += G * U) {
+            double x[U];
 #pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) {
-            const double m2 = __shfl_xor(m, o);
-            const int i2 = __shfl_xor(idx, o);
-            const int n2 = __shfl_xor((int)isn, o);
-            bool take;
-            if (i2 == 0x7fffffff) take = false;
-            else if (idx == 0x7fffffff) take = true;
-            else if (isn || n2) take = n2 && (!isn || i2 < idx);
-            else if (want_min ? (m2 < m) : (m2 > m)) take = true;
-            else if (m2 == m) take = i2 < idx;
-            else take = false;
-            if (take) { m = m2; idx = i2; isn = n2 != 0; }
+            for (int u = 0; u < U; ++u) { const int i = i0 + u * G; x[u] = p[i < n ? i : i0]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * G;
+                const int better = want_min ? !(x[u] >= m) : !(x[u] <= m);            // also true for a NaN
+                const int upd = (i < n) & (isn ^ 1) & ((idx == kNone) | better);
+                m = upd ? x[u] : m;
+                idx = upd ? i : idx;
+                isn |= upd & (int)(x[u] != x[u]);
+            }
         }
-        return idx;
+        const int first_nan = group_min_i32<G>(isn ? idx : kNone);
+        const int plain = (idx != kNone) & (isn ^ 1);
+        const double inf = __longlong_as_double(0x7ff0000000000000LL);
+        const double mine = plain ? m : (want_min ? inf : -inf);
+        const double ext = group_ext_f64<G>(mine, want_min);
+        const int best = group_min_i32<G>((plain & (int)(mine == ext)) ? idx : kNone);
+        return first_nan != kNone ? first_nan : best;
     }
 };
 
@@ -388,11 +407,17 @@ struct GroupLeaf {                                               // a piece of a
         const int j = threadIdx.x & 7;
         const int lim = n - (n % 8);
         double r = f(off + j);
-        for (int i = 8 + j; i < lim; i += 8) r = r + f(off + i);
-        const int g0 = (threadIdx.x & 63) & ~(G - 1);            // first lane of this group in the wave
-        const double r0 = __shfl(r, g0 + 0), r1 = __shfl(r, g0 + 1), r2 = __shfl(r, g0 + 2), r3 = __shfl(r, g0 + 3);
-        const double r4 = __shfl(r, g0 + 4), r5 = __shfl(r, g0 + 5), r6 = __shfl(r, g0 + 6), r7 = __shfl(r, g0 + 7);
-        double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        int i = 8 + j;
+        for (; i + 24 < lim; i += 32) {                              // four terms fetched before the first is added (same order of adds)
+            const double t0 = f(off + i), t1 = f(off + i + 8), t2 = f(off + i + 16), t3 = f(off + i + 24);
+            r = r + t0; r = r + t1; r = r + t2; r = r + t3;
+        }
+        for (; i < lim; i += 8) r = r + f(off + i);
+        // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) with r_j on lane j of every eight: lane ^ 1, lane ^ 2, then the
+        // mirrored lane of the eight, which holds the other quad's sum (IEEE addition commutes bit for bit)
+        double res = r + dpp_f64<kDppXor1>(r);
+        res = res + dpp_f64<kDppXor2>(res);
+        res = res + dpp_f64<kDppHalfMirror>(res);
         for (int i = lim; i < n; ++i) res = res + f(off + i);
         return res;
     }
@@ -439,6 +464,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LFA_PEAKS_W
                                                Job j, const LfaRoi* rois, const int32_t* counts, int slots,
                                                const int32_t* roi_lut, int n_luts) {
     extern __shared__ __align__(16) unsigned char smem[];
+#ifdef LFA_PEAKS_CLOCK
+    const long long ck0 = __builtin_readcyclecounter();
+#endif
     const int ppb = blockDim.x / G;
     const int slot = threadIdx.x / G, lg = threadIdx.x & (G - 1);
     double* sp = (double*)smem + (int64_t)slot * lstride;
@@ -462,14 +490,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LFA_PEAKS_W
     const double* g = profiles + (int64_t)(valid ? i : 0) * stride;
     const bool work = valid && !bad;
     const bool use_lds = lstride > 0 && len <= lstride;
-    if (work && use_lds) for (int k = lg; k < len; k += G) sp[k] = g[k];
+#ifdef LFA_PEAKS_CLOCK
+    const long long ck1 = __builtin_readcyclecounter();
+#endif
+    if (work && use_lds) {
+        constexpr int U = 8;                                         // eight loads in flight per lane (one at a time: 11 000 of the
+        for (int k0 = lg; k0 < len; k0 += G * U) {                   //  kernel's 47 000 clocks per profile went into this copy)
+            double x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int k = k0 + u * G; x[u] = g[k < len ? k : k0]; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int k = k0 + u * G; if (k < len) sp[k] = x[u]; }
+        }
+    }
     __syncthreads();
+#ifdef LFA_PEAKS_CLOCK
+    const long long ck2 = __builtin_readcyclecounter();
+#endif
     if (bad) { if (lg == 0) store_bad(&out[i], len); return; }
     if (!work) return;
     // the search is inlined for the LDS copy of the profile (ds_read on the dependent chains); the profile that does not
     // fit the LDS slots (more than ~8000 rows) takes an out-of-line copy of the same code on the global pointer
     if (use_lds) peaks_search<G>(sp, len, inverse, window, two, rng, lg == 0 ? &out[i] : nullptr);
     else peaks_search_global<G>(g, len, inverse, window, two, rng, lg == 0 ? &out[i] : nullptr);
+#ifdef LFA_PEAKS_CLOCK
+    // dev aid: phase lengths in shader clocks instead of the areas (results are wrong on purpose)
+    const long long ck3 = __builtin_readcyclecounter();
+    if (lg == 0) { out[i].area[0] = (double)(ck1 - ck0) + 1e-6 * (double)(ck2 - ck1); out[i].area[1] = (double)(ck3 - ck2); }
+#endif
 }
 
 // LDS plan: `lstride` float64 slots per profile, ONE wave per block (round 3: blocks of four waves ended with their slowest

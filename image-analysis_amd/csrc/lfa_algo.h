@@ -21,6 +21,17 @@
 #define LFA_HD_NOINLINE inline
 #endif
 
+// dev aid (tools/r3_peaks_clock.py, variant build -DLFA_PEAKS_CLOCK): shader clocks per phase of the peak search, summed over
+// the waves' first lanes into lfa_ck[]; expands to nothing in the product build
+#if defined(LFA_PEAKS_CLOCK) && defined(__HIP_DEVICE_COMPILE__)
+extern __device__ unsigned long long lfa_ck[16 * 1024];
+#define LFA_CK_BEGIN() long long ck_prev_ = __builtin_readcyclecounter()
+#define LFA_CK(k) do { const long long t_ = __builtin_readcyclecounter(); if ((threadIdx.x & 63) == 0) atomicAdd(&lfa_ck[(k) * 1024 + (blockIdx.x & 1023)], (unsigned long long)(t_ - ck_prev_)); ck_prev_ = __builtin_readcyclecounter(); } while (0)
+#else
+#define LFA_CK_BEGIN() do {} while (0)
+#define LFA_CK(k) do {} while (0)
+#endif
+
 namespace lfa {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -193,14 +204,19 @@ struct SeqSum {
 // device (k_profile.hip GroupWalk, GroupSum) -- same values, same rounding order.
 template <class WK, class SM>
 LFA_HD Peak analyze_peaks_at_t(const double* p, int n, int peak, bool inverse, int window, const WK& walk, const SM& sum) {
+    LFA_CK_BEGIN();
     int ws = peak - window; if (ws < 0) ws = 0;
     int we = peak + window + 1; if (we > n) we = n;
     const double thr = sum(ArrAt{p}, ws, we - ws) / (double)(we - ws);
+    LFA_CK(0);
     const int s = walk(p, n, peak, -1, thr, inverse);
     const int e = walk(p, n, peak, +1, thr, inverse);
+    LFA_CK(1);
     const int m = e - s + 1;
     const double seg = sum(TrapzAt{p + s}, 0, m - 1);
+    LFA_CK(2);
     const double base = sum(TrapzLin{Linspace(p[s], p[e], m)}, 0, m - 1);
+    LFA_CK(3);
     Peak r;
     r.start = s; r.end = e;
     r.area = inverse ? (base - seg) : (seg - base);
@@ -237,7 +253,11 @@ LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool 
     TwoPeaks out;
     out.n = 0;
     if (n <= 0) return out;
-    const Peak a = analyze_peaks_at_t(p, n, argext(p, n, inverse), inverse, window, walk, sum);
+    LFA_CK_BEGIN();
+    const int i0 = argext(p, n, inverse);
+    LFA_CK(4);
+    const Peak a = analyze_peaks_at_t(p, n, i0, inverse, window, walk, sum);
+    LFA_CK(5);
     out.n = 1; out.pk[0] = a; out.pk[1] = a;
     const int s = a.start, e = a.end;
     if (!(s > 1 && e < n - 2)) return out;
@@ -256,6 +276,7 @@ LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool 
     const double* right = p + right_off;
     const int il = argext(p, left_len, inverse);
     const int ir = argext(right, right_len, inverse);
+    LFA_CK(6);
     const bool take_left = inverse ? (right[ir] > p[il]) : (right[ir] < p[il]);
     // one call site for both sides (the function is inlined on the device: every call site is a full copy)
     Peak b = analyze_peaks_at_t(take_left ? p : right, take_left ? left_len : right_len, take_left ? il : ir, inverse, window, walk, sum);
@@ -266,6 +287,7 @@ LFA_HD TwoPeaks two_peaks_t(const double* p, int n, bool inverse, int rng, bool 
         b.start += off;
         b.end += off;
     }
+    LFA_CK(7);
     const int s2 = b.start, e2 = b.end;
     if ((s2 <= s && e2 > s) || (s2 <= e && e2 > e) || (s2 >= s && e2 <= e)) return out;
     out.n = 2; out.pk[1] = b;

@@ -42,6 +42,47 @@ __device__ inline double wave_max_f64(double v) {
     return v;
 }
 
+// ---- reductions inside groups of G = 8 / 16 / 32 / 64 consecutive lanes (every lane ends with its group's result) -----------
+// On the DPP data path while the partner lies in the lane's own row of 16: quad_perm for lane ^ 1 and lane ^ 2, then
+// row_half_mirror (lane i <-> 7 - i of its eight) and row_mirror (i <-> 15 - i of its sixteen) -- for an operation that is
+// commutative and associative BIT FOR BIT (integer min, float max / min of NaN-free values, and a float add of two values
+// each lane pair holds symmetrically) a mirrored partner serves as well as lane ^ 4 / lane ^ 8, because after the steps
+// before it every lane of the partner's quad / half-row holds the same partial result.  Rows are joined with ds_bpermute
+// (__shfl_xor 16 / 32).  One v_mov_dpp per 32 bits and step instead of a ds_bpermute round trip (~130 clocks) each.
+// A lane whose partner is switched off (another group of the wave that has left) keeps its own value.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i32<CTRL>((int)(uint32_t)b), hi = dpp_i32<CTRL>((int)(uint32_t)((unsigned long long)b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
+template <int G>
+__device__ __forceinline__ int group_min_i32(int v) {
+    v = min(v, dpp_i32<kDppXor1>(v));
+    v = min(v, dpp_i32<kDppXor2>(v));
+    v = min(v, dpp_i32<kDppHalfMirror>(v));
+    if (G >= 16) v = min(v, dpp_i32<kDppMirror>(v));
+    if (G >= 32) v = min(v, __shfl_xor(v, 16));
+    if (G >= 64) v = min(v, __shfl_xor(v, 32));
+    return v;
+}
+// largest (want_min: smallest) of the group's values; no NaN among them
+template <int G>
+__device__ __forceinline__ double group_ext_f64(double v, bool want_min) {
+    auto pick = [want_min](double a, double b) { return (want_min ? (b < a) : (b > a)) ? b : a; };
+    v = pick(v, dpp_f64<kDppXor1>(v));
+    v = pick(v, dpp_f64<kDppXor2>(v));
+    v = pick(v, dpp_f64<kDppHalfMirror>(v));
+    if (G >= 16) v = pick(v, dpp_f64<kDppMirror>(v));
+    if (G >= 32) v = pick(v, __shfl_xor(v, 16));
+    if (G >= 64) v = pick(v, __shfl_xor(v, 32));
+    return v;
+}
+
 // ---- loads -----------------------------------------------------------------------------------------------------------
 // 48 bytes (16 colour pixels) from a 16-byte aligned address
 __device__ inline void load48(const uint8_t* p, uint32_t (&w)[12]) {
