@@ -109,7 +109,7 @@ def secondary_child(args):
     configuration, configs[2] and configs[3] came out 10-15 % lower (placement of their buffers among what the earlier
     run had held) -- alone they repeat within 1 %."""
     out = {}
-    for name in ("big", "u16", "u16real", "rois", "gauss", "lines"):
+    for name in ("big", "u16", "u16real", "photo", "rois", "gauss", "lines"):
         cmd = [sys.executable, os.path.join(ROOT, "benchmarks_configs.py"), name, "--json", "--steps", str(args.config_steps)]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         if r.returncode != 0:

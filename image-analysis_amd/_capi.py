@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("LFA_LIB_PATH") or os.path.join(_HERE, "liblfa_hip.so"
 
 LFA_U8, LFA_U16, LFA_F64 = 0, 1, 6
 ELEM_CODES = {"uint8": 0, "uint16": 1, "int8": 2, "int16": 3, "int32": 4, "uint32": 5, "float64": 6}   # lfa.h LFA_E_*
-DBG_MASK, DBG_OPENED, DBG_LABELS, DBG_TABLE, DBG_HIST, DBG_PLANE, DBG_ONEPASS = 0, 1, 2, 3, 4, 5, 6
+DBG_MASK, DBG_OPENED, DBG_LABELS, DBG_TABLE, DBG_HIST, DBG_PLANE, DBG_ONEPASS, DBG_GREY = 0, 1, 2, 3, 4, 5, 6, 7
 GRAY_NVARIANTS = 6
 
 # numpy mirrors of the C structs (align=True reproduces the C layout)
@@ -735,6 +735,13 @@ class Engine:
         torch = _torch()
         out = torch.zeros(1, dtype=torch.int32, device=self.device)
         _check(lib.lfa_debug_fetch(self._h, image_index, DBG_PLANE, out.data_ptr(), 4, current_stream_ptr(self.device)))
+        return bool(out.cpu().numpy()[0])
+
+    def debug_grey_path(self, image_index):
+        """True if image `image_index` of the last call went through the equal-channel path (LFA_DBG_GREY)."""
+        torch = _torch()
+        out = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _check(lib.lfa_debug_fetch(self._h, image_index, DBG_GREY, out.data_ptr(), 4, current_stream_ptr(self.device)))
         return bool(out.cpu().numpy()[0])
 
     def debug_one_pass(self):

@@ -452,6 +452,12 @@ hipError_t launch_debug(const Job& j, int image, int what, void* out, int64_t ou
             else e = hipMemsetAsync(out, 0, 4, s);
             if (e != hipSuccess) return e;
             break;
+        case LFA_DBG_GREY:
+            if (out_bytes < 4) return hipErrorInvalidValue;
+            if (j.grey_mode) e = hipMemcpyAsync(out, j.edges_i + (int64_t)image * kEdgesI + kEdgesI_Grey, 4, hipMemcpyDeviceToDevice, s);
+            else e = hipMemsetAsync(out, 0, 4, s);
+            if (e != hipSuccess) return e;
+            break;
         default:
             return hipErrorInvalidValue;
     }

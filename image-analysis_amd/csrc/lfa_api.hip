@@ -151,6 +151,7 @@ struct LfaContext {
     uint32_t* plane_host = nullptr;        // pinned, kStatsWords words
     hipEvent_t plane_event = nullptr;
     bool plane_pending = false, plane_on = true;
+    bool grey_on = false;                  // most colour images of the last completed call had three equal channels (k_grey_hist)
     // uint16 images: the histogram pass needs no min/max pass before it when the bins are the pixel values themselves (one
     // pass less over the image); worth it while the values stay below the LDS table of k_hist_u16 (camera data of 12-14
     // bits).  Chosen from the largest value of the last completed uint16 call, which travels with the counters above.
@@ -317,6 +318,7 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
         } else if (h->debug_flags & 4) { j.u16_pred = 1; j.u16_ps = ps; j.u16_pa = 0; }
         j.u16_plane = (j.u16_pred && w.bins.bytes >= (size_t)n * (((size_t)H * W + 1) / 2) && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->u16_plane_on || (h->debug_flags & 4))) ? 1 : 0;
     }
+    j.grey_mode = (C == 3 && dtype == LFA_U8 && j.aligned16 && !(h->debug_flags & 2048) && (h->grey_on || (h->debug_flags & 1024))) ? 1 : 0;
     const bool rgb_plane = C == 3 && dtype == LFA_U8 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4));
     j.bins = (j.u16_plane || rgb_plane) ? (uint8_t*)w.bins.p : nullptr;
     j.maskT = (uint64_t*)w.maskT.p;
@@ -394,6 +396,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (!static_ws && h->plane_pending && (poll ? hipEventQuery(h->plane_event) == hipSuccess : hipEventSynchronize(h->plane_event) == hipSuccess)) {
         h->plane_pending = false;
         if (h->plane_host[1]) h->plane_on = 2u * h->plane_host[0] >= h->plane_host[1];
+        if (h->plane_host[1]) h->grey_on = 2u * h->plane_host[11] >= h->plane_host[1];
         if (h->plane_host[3]) { h->u16_max = (int)h->plane_host[2]; h->u16_one_pass = h->plane_host[2] < (uint32_t)lfa::kLdsBinsU16; }
         if (h->plane_host[4]) h->win_hint = (int)h->plane_host[4];
         if (h->plane_host[8]) {
@@ -416,7 +419,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         // no events either: nothing is recorded for, or awaited from, other handles (lfa_stream_wait_passes /
         // lfa_chain_passes do not see static calls), so the call is kernels and memsets on `s` only and can be captured
         j.passes_event = nullptr; j.wait_event = nullptr;
-        j.plane_stats = nullptr; j.bins = nullptr; j.u16_plane = 0; j.hist_abs = 0; j.win_hint = 0;
+        j.plane_stats = nullptr; j.bins = nullptr; j.u16_plane = 0; j.hist_abs = 0; j.win_hint = 0; j.grey_mode = 0;
         j.u16_lds_bins = lfa::kLdsBinsU16; j.u16_pred = 0; j.u16_pa = 0; j.u16_ps = 0;
         if (ws_rois) *ws_rois = (LfaRoi*)w.rois.p;
     } else {

@@ -150,6 +150,18 @@ __device__ inline double gray_u8(uint32_t p0, uint32_t p1, uint32_t p2) {
     return fma(x1, c1, x0 * c0) + x2 * c2;
 }
 
+// (rounding order as a run-time value: the few places that evaluate a handful of grays per image)
+__device__ inline double gray_u8_rt(int variant, uint32_t p0, uint32_t p1, uint32_t p2) {
+    switch (variant) {
+        case 0: return gray_u8<0>(p0, p1, p2);
+        case 1: return gray_u8<1>(p0, p1, p2);
+        case 2: return gray_u8<2>(p0, p1, p2);
+        case 3: return gray_u8<3>(p0, p1, p2);
+        case 4: return gray_u8<4>(p0, p1, p2);
+        default: return gray_u8<5>(p0, p1, p2);
+    }
+}
+
 // the same dot product on already scaled values, for the pixel types that have no integer form: uint16 colour
 // (x_k = fl(pixel_k * fl(1/65535))), float64 colour (x_k = pixel_k: img_as_float leaves floats alone), float64 2-D (gray = pixel)
 template <int V>

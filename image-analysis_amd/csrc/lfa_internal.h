@@ -19,6 +19,8 @@ constexpr int kEdgesI_MaskCrit = 259;    // != 0: mask threshold critical -> flo
 constexpr int kEdgesI_Bins = 260;        // != 0: the image's class plane (Job::bins) is valid and k_mask may use it
 constexpr int kEdgesI_Class = 261;       // uint16 class plane: the class q of the image's threshold x_thr; bit 8: x_thr is the last value
                                          // of class q, so that class is clear as a whole and k_mask never looks at the frame (k_otsu_int)
+constexpr int kEdgesI_Grey = 262;        // colour uint8 images on the vector path: 1 while no pixel with unequal channel bytes has been seen
+                                         // (k_init_info sets it, k_minmax_rgb / k_grey_hist clear it)
 constexpr int kHostPowDoubles = 2 + 257 + 256;   // sizeof(LfaHostPow) / 8
 constexpr int kStatsWords = 12;          // Job::plane_stats
 constexpr int kAreaMin = 100;            // detection.py:81
@@ -49,7 +51,7 @@ struct Job {
     uint32_t* edges_i;       // [n][264]  the same as integer thresholds on G = 2125*b0 + 7154*b1 + 721*b2 (k_threshold.hip)
     hipEvent_t passes_event; // recorded on the launch stream right after the histogram pass (lfa_stream_wait_passes); may be null
     hipEvent_t wait_event;   // the image passes of this call start after it (lfa_chain_passes); may be null
-    uint32_t* plane_stats;   // [kStatsWords]  [4] longest analysis window of the call in rows (k_finalize); [0] colour images of this call whose mask could be decided from the class plane, [1] colour images
+    uint32_t* plane_stats;   // [kStatsWords]  [11] colour images of this call with three equal channels throughout; [4] longest analysis window of the call in rows (k_finalize); [0] colour images of this call whose mask could be decided from the class plane, [1] colour images
                              //      seen (k_otsu_rgb counts), [2] largest pixel value of the call's uint16 images, [3] uint16 images
                              //      seen (k_otsu_int); [5] sum, [8] number, [9] 65535 - smallest and [10] largest of the uint16 thresholds x_thr, [6] uint16 images whose
                              //      mask could be decided from the class plane around u16_pa, [7] images that test was made on;
@@ -88,6 +90,8 @@ struct Job {
     uint32_t* rowsum;        // [n][rowsum_cap] integer row sums of analysis windows (written by k_box_sums)
     int32_t rowsum_cap;      // 16 * H
     int32_t* slot_rs_off;    // [n][max_strips] the same offset per output strip slot (written by k_finalize)
+    int32_t grey_mode;       // colour uint8 images are expected to have three equal channels (what cv2.imread makes of a grey file):
+                             //         k_grey_hist takes their byte histogram in ONE pass and k_minmax_rgb / k_hist_rgb skip them
     const double* host_pow;  // [n] LfaHostPow records (lfa_set_host_pow) or null: vmin, vmax, 257 gray-space edges, 256 gray-space thresholds
     const uint8_t* lut8;     // [256]
     const uint16_t* lut16;   // [65536]

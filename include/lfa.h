@@ -183,6 +183,11 @@ int lfa_set_host_pow(LfaHandle h, const LfaHostPow* tables, int n);
  * bit6 (64): lfa_detect_lines_batch keeps the float64 Gaussian image (8 more bytes per pixel) for
  * lfa_lines_debug_fetch(LFA_LDBG_GAUSS); bit7 (128): its labelling looks every pixel's class up in the class table (by
  * default the class is computed from the level where the table is "0, then one class per level, then constant").
+ * bit10 (1024): colour uint8 calls take the equal-channel ("grey") mode whatever the handle's last call held; bit11 (2048):
+ * never.  By default a handle takes it once at least half of the colour images of its last completed call had three equal
+ * channels in every pixel -- what cv2.imread hands the reference for a grey file (detection.py:454): one pass then takes the
+ * byte histogram and the min/max and histogram passes skip the image; an image with a single unequal pixel takes the
+ * ordinary passes.  Results are identical either way.
  * bit8 (256) / bit9 (512): k_edges_rgb moves every interior gray-space histogram edge it computed one double up / down --
  * what a pow() whose last bit differs would do -- so that the tests can show an image with a pixel exactly on an edge
  * going wrong without lfa_set_host_pow and right with it (tables from lfa_set_host_pow are never touched). */
@@ -351,6 +356,8 @@ int lfa_lines_debug_fetch(LfaHandle h, int image_index, int what, void* out, int
 #define LFA_DBG_TABLE   3   /* int32 K*5 : minr,minc,maxr,maxc,area per label (regionprops, detection.py:71-73) */
 #define LFA_DBG_HIST    4   /* uint32 nb : histogram counts (nb = 256 colour / uint8, xmax-xmin+1 uint16; input domain) */
 #define LFA_DBG_PLANE   5   /* int32 1   : 1 if the mask of this image was decided from the class plane, else 0           */
+#define LFA_DBG_GREY    7   /* int32 1   : 1 if this colour image went through the equal-channel path (byte histogram, no min/max
+                                              and no histogram pass), else 0 */
 #define LFA_DBG_ONEPASS 6   /* int32 1   : 1 if the last call took the one-pass uint16 histogram (no min/max pass), else 0 */
 
 /* Rasterise intermediate `what` of image `image_index` of the LAST detect/analyze call into `out` (device). */

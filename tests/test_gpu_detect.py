@@ -203,6 +203,8 @@ def test_class_plane_is_chosen_per_image_and_per_call(capi):
     Every intermediate is checked against the oracle whichever way the choice goes."""
     rng = np.random.default_rng(99)
     eng = capi.Engine(device=0, max_h=192, max_w=256, max_batch=4)
+    eng.set_debug_flags(2048)            # (these images have three equal channels: keep the handle out of the equal-channel mode,
+                                         #  which needs no class plane -- this test is about the plane)
     try:
         valley = np.stack([_valley_image(rng) for _ in range(4)])
         photo = np.stack([_photo_image(rng) for _ in range(4)])
@@ -218,7 +220,7 @@ def test_class_plane_is_chosen_per_image_and_per_call(capi):
         assert run(photo) == [False] * 4                            # 3 of 4 could before: plane still written, nobody uses it
         assert run(valley) == [False] * 4                           # last call: 0 of 4 could -> this call wrote no plane
         assert run(valley) == [True] * 4                            # last call: 4 of 4 could have -> plane back on
-        eng.set_debug_flags(4)
+        eng.set_debug_flags(4 | 2048)
         assert run(photo) == [True] * 4                             # forced: the fix-up loop settles the pixels of the class
         eng.set_debug_flags(0)
     finally:
@@ -763,3 +765,72 @@ def test_ambiguous_images_in_a_stream_and_in_analyze_batch(capi, monkeypatch):
             assert np.array_equal(out[i][k][1], wp) and np.array_equal(got[i][2][k], wp)
     crops = det.detect_lateral_flow_tests(tie)
     assert [c.shape[:2] for c in crops] == [(min(b, H) - a, min(e, W) - c) for a, b, c, e in want[1]]
+
+
+def test_equal_channel_images_take_one_pass_and_match_the_oracle(capi, golden_dir):
+    """cv2.imread hands the reference three equal channels for every grey file (detection.py:454; all of its sample JPEGs):
+    gray is then a function of the byte value, so ONE pass (k_grey_hist: byte histogram + a check of every pixel's channels)
+    replaces the min/max and the histogram pass.  Forced on for a mixed batch: a grey photo, a colour image (falls back to
+    the ordinary passes), a grey image with one unequal pixel at its very end (falls back too), a constant grey image, a
+    grey image with 2 values; every intermediate against the oracle, and LFA_DBG_GREY tells which way each image went."""
+    from image_analysis_amd.synth import synth_rgb
+    g = np.load(os.path.join(golden_dir, "image1_decoded.npz"))["gray"][:256, :320]
+    H, W = g.shape
+    grey = np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
+    colour = synth_rgb(H, W, 5, 21)
+    almost = grey.copy(); almost[-1, -1, 2] ^= 1
+    const = np.full((H, W, 3), 77, np.uint8)
+    two = np.where(g[:, :, None] > 100, np.uint8(200), np.uint8(30)).repeat(3, axis=2)
+    imgs = [grey, colour, almost, const, np.ascontiguousarray(two)]
+    mm_r, mm_c = gui_params(grey)
+    e = capi.Engine(device=0, max_h=H, max_w=W, max_batch=len(imgs))
+    try:
+        for flags in (1024, 1024 | 1, 1024 | 4):
+            e.set_debug_flags(flags)
+            for i, im in enumerate(imgs):                     # one by one: the debug fetches look at the last call
+                check_detect(capi, e, im, mm_r, mm_c)
+                assert e.debug_grey_path(0) == (i in (0, 3, 4)), (flags, i)
+            res = e.detect(np.stack(imgs), mm_r, mm_c)
+            assert [e.debug_grey_path(i) for i in range(len(imgs))] == [True, False, False, True, True]
+            for i, im in enumerate(imgs):
+                d = O.detect_debug(im, mm_r, mm_c)
+                got = [[int(s["minr"]), int(s["maxr"]), int(s["minc"]), int(s["maxc"])] for s in res[0][i]]
+                assert got == d["strips"] and capi.host_threshold(res[1][i], True) == d["threshold"], (flags, i)
+                assert int(res[1][i]["n_labels"]) == d["n_labels"]
+        e.set_debug_flags(2048)
+        check_detect(capi, e, grey, mm_r, mm_c)
+        assert not e.debug_grey_path(0)
+    finally:
+        e.close()
+
+
+def test_a_handle_finds_grey_batches_by_itself(capi, golden_dir):
+    """The mode follows the handle's last completed call: the min/max pass notices images whose channels are equal throughout,
+    the count travels with the handle's other counters, and the next call takes the one-pass path while at least half of
+    the colour images were grey; a colour batch switches it off again.  Results equal the oracle at every step."""
+    from image_analysis_amd.synth import synth_rgb
+    g = np.load(os.path.join(golden_dir, "image1_decoded.npz"))["gray"][:192, :256]
+    H, W = g.shape
+    greys = np.stack([np.repeat(np.roll(g, 7 * k, axis=1)[:, :, None], 3, axis=2) for k in range(3)])
+    colours = np.stack([synth_rgb(H, W, 4, 30 + k) for k in range(3)])
+    mm_r, mm_c = gui_params(g)
+    e = capi.Engine(device=0, max_h=H, max_w=W, max_batch=3)
+    try:
+        def run(batch):
+            strips, info = e.detect(batch, mm_r, mm_c)
+            path = [e.debug_grey_path(i) for i in range(len(batch))]
+            for i, im in enumerate(batch):
+                d = O.detect_debug(im, mm_r, mm_c)
+                assert [[int(s["minr"]), int(s["maxr"]), int(s["minc"]), int(s["maxc"])] for s in strips[i]] == d["strips"]
+                assert capi.host_threshold(info[i], True) == d["threshold"] and int(info[i]["n_labels"]) == d["n_labels"]
+            return path
+        assert run(greys) == [False] * 3              # first call: the ordinary passes, which count the grey images
+        assert run(greys) == [True] * 3               # now in grey mode
+        mixed = np.stack([greys[0], colours[0], greys[1]])
+        assert run(mixed) == [True, False, True]      # still on (3 of 3 grey last time); the colour image falls back
+        assert run(colours) == [False] * 3            # on (2 of 3), every image falls back
+        assert run(colours) == [False] * 3            # off (0 of 3)
+        assert run(greys) == [False] * 3
+        assert run(greys) == [True] * 3
+    finally:
+        e.close()

@@ -24,7 +24,7 @@ def _check(capi, eng, im, mm_r, mm_c, L, thr_want, mask_sha, opened_sha, labels_
     H, W = im.shape[:2]
     strips, info = eng.detect(im[None], mm_r, mm_c, L)
     inf = info[0]
-    assert inf["status"] == 0 and inf["ambiguous"] == 0
+    assert (inf["status"] & 3) == 0 and inf["ambiguous"] == 0
     thr = capi.host_threshold(inf, im.ndim == 3 or im.dtype == np.float64)       # (float images take the colour path's float64 arithmetic)
     assert np.asarray(thr, dtype=thr_want.dtype).tobytes() == thr_want.tobytes(), (thr, thr_want)
     assert np.array_equal(sha(eng.debug(0, capi.DBG_MASK, H, W)), mask_sha)
@@ -47,7 +47,9 @@ def test_hip_detect_equals_the_reference_run_over_vendored_skimage(capi, name):
     eng = capi.Engine(device=0, max_h=im.shape[0], max_w=im.shape[1], max_batch=1)
     try:
         # default path choice, class plane forced (colour / uint16), class plane off, float64 compare path (colour)
-        for flags in ((0, 4, 2, 1) if im.ndim == 3 else (0, 0, 4, 2)):
+        # colour uint8: the equal-channel mode forced on as well (grey fixtures take its one-pass path, the others fall back to
+        # the ordinary passes inside it), alone and with the float64 compare path
+        for flags in ((0, 4, 2, 1, 1024, 1024 | 1, 2048) if im.ndim == 3 else (0, 0, 4, 2)):
             eng.set_debug_flags(flags)
             _check(capi, eng, im, mm_r, mm_c, L, G[f"{name}__threshold"], G[f"{name}__mask_sha"], G[f"{name}__opened_sha"],
                    G[f"{name}__labels_sha"], int(G[f"{name}__n_labels"]), int(G[f"{name}__label00"]), G[f"{name}__table"],
