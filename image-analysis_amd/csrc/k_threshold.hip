@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void k_minmax_rgb(Job j) {
     int64_t done = 0;
     uint32_t* grey_flag = j.edges_i + (int64_t)img * kEdgesI + kEdgesI_Grey;
     if (j.grey_mode && *grey_flag) return;            // k_grey_hist found three equal channels throughout: k_edges_rgb has the extremes
-    uint32_t notgrey = 0;                             // otherwise this pass looks for such images on the way (the handle's next call)
+    uint32_t notgrey = 0;                             // otherwise this pass looks out for such images on the way (for the handle's next call)
     if (j.aligned16) {
         const int64_t ng = npix >> 4;                 // groups of 16 pixels = 48 bytes
         // lane-private record of the extreme it has seen (G, byte triple, float gray); wave-wide bounds Wlo / Whi (the best G
@@ -368,7 +368,9 @@ __global__ __launch_bounds__(256) void k_minmax_rgb(Job j) {
                 const int i = (3 * k) >> 2, sft = (3 * k) & 3;
                 return sft == 0 ? w[i] : (sft == 1 ? (w[i] >> 8) : __builtin_amdgcn_alignbyte(w[i + 1 < 12 ? i + 1 : i], w[i], sft));
             };
-            if (!j.grey_mode) notgrey |= not_grey16(w);
+            // (a hint for the handle's next call, so one round in four is looked at: +1 % on this pass instead of +4 %; the
+            //  equal-channel pass itself checks every pixel)
+            if (!j.grey_mode && ((r >> 2) & 3) == 0) notgrey |= not_grey16(w);
             bool reach = false;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {

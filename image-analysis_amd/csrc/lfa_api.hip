@@ -151,7 +151,12 @@ struct LfaContext {
     uint32_t* plane_host = nullptr;        // pinned, kStatsWords words
     hipEvent_t plane_event = nullptr;
     bool plane_pending = false, plane_on = true;
-    bool grey_on = false;                  // most colour images of the last completed call had three equal channels (k_grey_hist)
+    // Equal-channel ("grey") mode: on while at least half of the colour images of the last completed call had three equal
+    // channels.  Outside the mode that count comes from a sampled look (k_minmax_rgb, one round in four), inside it from
+    // every pixel (k_grey_hist); when the mode was on and the exact count says "not grey" -- images that are grey where the
+    // sample looks and coloured elsewhere -- the handle stays out of the mode for the next four calls.
+    bool grey_on = false, pending_grey = false;
+    int grey_backoff = 0;
     // uint16 images: the histogram pass needs no min/max pass before it when the bins are the pixel values themselves (one
     // pass less over the image); worth it while the values stay below the LDS table of k_hist_u16 (camera data of 12-14
     // bits).  Chosen from the largest value of the last completed uint16 call, which travels with the counters above.
@@ -396,7 +401,12 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (!static_ws && h->plane_pending && (poll ? hipEventQuery(h->plane_event) == hipSuccess : hipEventSynchronize(h->plane_event) == hipSuccess)) {
         h->plane_pending = false;
         if (h->plane_host[1]) h->plane_on = 2u * h->plane_host[0] >= h->plane_host[1];
-        if (h->plane_host[1]) h->grey_on = 2u * h->plane_host[11] >= h->plane_host[1];
+        if (h->plane_host[1]) {
+            const bool mostly = 2u * h->plane_host[11] >= h->plane_host[1];
+            if (h->pending_grey && !mostly) h->grey_backoff = 4;
+            else if (h->grey_backoff > 0) --h->grey_backoff;
+            h->grey_on = mostly && h->grey_backoff == 0;
+        }
         if (h->plane_host[3]) { h->u16_max = (int)h->plane_host[2]; h->u16_one_pass = h->plane_host[2] < (uint32_t)lfa::kLdsBinsU16; }
         if (h->plane_host[4]) h->win_hint = (int)h->plane_host[4];
         if (h->plane_host[8]) {
@@ -442,6 +452,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
     if (j.plane_stats && !h->plane_pending) {
         LFA_HIP(hipMemcpyAsync(h->plane_host, h->plane_stats.p, lfa::kStatsWords * 4, hipMemcpyDeviceToHost, s));
         h->pending_had_pred = h->u16_have_pred;
+        h->pending_grey = j.grey_mode != 0;
         LFA_HIP(hipEventRecord(h->plane_event, s));
         h->plane_pending = true;
     }

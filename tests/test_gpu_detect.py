@@ -829,8 +829,15 @@ def test_a_handle_finds_grey_batches_by_itself(capi, golden_dir):
         mixed = np.stack([greys[0], colours[0], greys[1]])
         assert run(mixed) == [True, False, True]      # still on (3 of 3 grey last time); the colour image falls back
         assert run(colours) == [False] * 3            # on (2 of 3), every image falls back
-        assert run(colours) == [False] * 3            # off (0 of 3)
-        assert run(greys) == [False] * 3
+        assert run(colours) == [False] * 3            # off (0 of 3, counted on every pixel while the mode was on: out for this and three more calls)
+        for _ in range(3):
+            assert run(greys) == [False] * 3
         assert run(greys) == [True] * 3
+        # grey where the sampled look of the min/max pass falls, coloured elsewhere is possible: the mode then costs a wasted pass
+        # once, finds the exact count at odds with the hint, and backs off -- results are right throughout (run() checks them)
+        speck = greys.copy()
+        speck[:, 100, 37, 1] ^= 0x10
+        seen = [run(speck) for _ in range(7)]
+        assert all(p == [False] * 3 for p in seen)
     finally:
         e.close()
