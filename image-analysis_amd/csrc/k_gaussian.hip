@@ -212,7 +212,10 @@ static hipError_t launch_shape(const Job& j, const GaussW& gw, OUT* out, hipStre
     if constexpr (sizeof(OUT) == 4 && ((2 * R * C) % 4) == 0) {
         if (((j.W * C) & 3) == 0 && j.aligned16 && (((uintptr_t)out) & 15) == 0) return launch_f32<PIX, C, R>(j, gw, (float*)out, s);
     }
-    if (C == 3) return launch_t<PIX, OUT, C, R, 8, 512>(j, gw, out, s);
+#ifndef LFA_GAUSS_TH_RGB
+#define LFA_GAUSS_TH_RGB 8
+#endif
+    if (C == 3) return launch_t<PIX, OUT, C, R, LFA_GAUSS_TH_RGB, 512>(j, gw, out, s);
     return launch_t<PIX, OUT, C, R, 8, 256>(j, gw, out, s);
 }
 

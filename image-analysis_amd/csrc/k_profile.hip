@@ -5,6 +5,7 @@
 // integer images this path handles that is an exact integer row sum and one float64 division.  The peak logic is the
 // shared sequential code of lfa_algo.h (bit-for-bit numpy summation order) run by a group of 16 or 64 lanes with a
 // group-parallel first-extremum search.
+#include <algorithm>
 #include <cstdlib>
 
 #include "lfa_internal.h"
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
                                                  LfaPeaks* peaks, int lstride, const uint8_t* luts, const int32_t* roi_lut,
                                                  int n_luts, const int32_t* skip_if_sorted) {
     extern __shared__ __align__(16) unsigned char smem[];
-    if (skip_if_sorted && skip_if_sorted[0] == 1) return;        // k_profile_band has done the profiles (launch_profiles)
+    if (skip_if_sorted && skip_if_sorted[0] == 0) return;        // sorted ROI array: k_profile_band has done the profiles (launch_profiles)
     const int rpb = blockDim.x / G;                              // ROIs per block
     const int slot = threadIdx.x / G, lg = threadIdx.x & (G - 1);
     double* sp = (double*)smem + (int64_t)slot * lstride;
@@ -296,21 +297,23 @@ __global__ __launch_bounds__(256) void k_profile(Job j, const LfaRoi* rois, int 
 // 16-lane group, so no accumulation order and no atomics are involved.
 // ---------------------------------------------------------------------------------------------------------------
 
-// One block.  idx[0] = 1 iff rois[].image is non-decreasing; idx[1 + k] = first ROI with image >= k, k = 0..n.
-__global__ __launch_bounds__(1024) void k_roi_index(const LfaRoi* rois, int n_rois, int n_images, int32_t* idx) {
+// idx[0] (cleared by the launcher beforehand) becomes 1 iff rois[].image somewhere DEcreases; idx[1 + k] = first ROI with image
+// >= k, k = 0..n: thread i writes the entries of the images (image[i-1], image[i]] -- each entry has exactly one writer when the
+// array is sorted, and nobody reads them when it is not.  (One 1024-thread block walked the whole array in rounds 1-2: 47 us
+// per call of 65 536 ROIs, 7 % of configs[4]'s step.)
+__global__ __launch_bounds__(256) void k_roi_index(const LfaRoi* rois, int n_rois, int n_images, int32_t* idx) {
     int unsorted = 0;
-    for (int i = threadIdx.x; i < n_rois; i += blockDim.x) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_rois; i += gridDim.x * blockDim.x) {
         const int cur = rois[i].image;
         const int prev = i ? rois[i - 1].image : -1;
         if (cur < prev) unsorted = 1;
         // images (prev, cur] start at i (clipped to the images there are)
         int lo = prev + 1 < 0 ? 0 : prev + 1, hi = cur < n_images ? cur : n_images;
         for (int k = lo; k <= hi; ++k) idx[1 + k] = i;
+        if (i == n_rois - 1)
+            for (int k = (cur + 1 < 0 ? 0 : cur + 1); k <= n_images; ++k) idx[1 + k] = n_rois;
     }
-    const int last = n_rois ? rois[n_rois - 1].image : -1;
-    for (int k = (last + 1 < 0 ? 0 : last + 1) + threadIdx.x; k <= n_images; k += blockDim.x) idx[1 + k] = n_rois;
-    unsorted = __syncthreads_or(unsorted);
-    if (threadIdx.x == 0) idx[0] = unsorted ? 0 : 1;
+    if (__any(unsorted) && (threadIdx.x & 63) == 0) idx[0] = 1;
 }
 
 // sum of the elements in bytes [b0, b0 + nbytes) of the row at `row` (16-byte aligned, LDS or global), by one lane:
@@ -360,9 +363,9 @@ __global__ __launch_bounds__(256) void k_profile_band(Job j, const LfaRoi* rois,
     uint4 hold[kBandRegs];
 #pragma unroll
     for (int u = 0; u < kBandRegs; ++u) hold[u] = (tid + 256 * u < n16) ? src[tid + 256 * u] : make_uint4(0u, 0u, 0u, 0u);
-    const int sorted = idx[0];
+    const int unsorted = idx[0];
     const int first = idx[1 + image], end = idx[2 + image];
-    if (sorted != 1) return;                                     // unsorted ROI array: k_profile runs instead
+    if (unsorted) return;                                        // unsorted ROI array: k_profile runs instead
     bool staged = false;
     for (int base = first; base < end; base += kBandList) {
         if (tid == 0) s_n = 0;
@@ -582,7 +585,9 @@ hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const i
     if (band_rows) {
         int rbl = 0;
         while ((1 << rbl) < band_rows) ++rbl;
-        LFA_LAUNCH("k_roi_index", k_roi_index, dim3(1), dim3(1024), 0, s, rois, n_rois, j.n, roi_idx);
+        const hipError_t e0 = hipMemsetAsync(roi_idx, 0, 4, s);
+        if (e0 != hipSuccess) return e0;
+        LFA_LAUNCH("k_roi_index", k_roi_index, dim3((unsigned)std::min<int64_t>(((int64_t)n_rois + 255) / 256, 1024)), dim3(256), 0, s, rois, n_rois, j.n, roi_idx);
         const dim3 grid((j.H + band_rows - 1) / band_rows, j.n);
         LFA_LAUNCH("k_profile_band", k_profile_band, grid, dim3(256), (size_t)band_rows * row_bytes, s, j, rois, roi_idx, rbl, stride,
                    profiles);
