@@ -80,7 +80,8 @@ class _Pipeline:
         self.info = capi.dev_bytes(B * 104, dev); self.rois = capi.dev_bytes(B * ms * 20, dev)
         self.prof = torch.empty(B * ms * self.stride, dtype=torch.float64, device=dev); self.peaks = capi.dev_bytes(B * ms * 40, dev)
         self.stagger = int(os.environ.get("LFA_STAGGER", "0"))
-        self.chain = NS > 1 and not self.stagger and os.environ.get("LFA_CHAIN", "1") == "1"
+        # (two lanes: free-running measured 3 % faster than chained on configs[3]; three lanes chained is bench.py's schedule)
+        self.chain = NS > 1 and not self.stagger and os.environ.get("LFA_CHAIN", "1" if NS >= 3 else "0") == "1"
         if self.chain:
             for i in range(NS):
                 capi._check(capi.lib.lfa_chain_passes(self.engs[i]._h, self.engs[i - 1]._h))
@@ -159,7 +160,7 @@ def bench_u16(B=1024, CH=256, pool=8, real=False, steps=10):
     return out
 
 
-def bench_big(B=128, CH=64, pool=4, steps=10, seed0=77, keep_pipeline=False, barrier=None):
+def bench_big(B=128, CH=int(os.environ.get("LFA_BIG_CHUNK", "64")), pool=4, steps=10, seed0=77, keep_pipeline=False, barrier=None):
     """configs[3]: 3072x4096 colour images (the reference's phone-camera size), 2 chunk streams like bench.py."""
     H, W = 3072, 4096
     pool_np = np.stack([synth.synth_rgb(H, W, 8, seed0 + i) for i in range(pool)])
