@@ -53,3 +53,35 @@ def test_two_ranks_started_by_bench_itself_rehearsal_on_one_gpu():
     assert c3["n_gpus"] == 2 and c3["images"] == 4 and c3["scaling"] == "weak"
     assert c3["gather"]["records"] == c3["strips_per_step"] == 2 * 4 * 8 and c3["gather"]["backend"].startswith("gloo")
     assert c3["images_per_s"] > 0 and 0 < c3["e2e_frac_hbm"] < 1
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[1], RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+dev = torch.device("cuda", 0)
+dist.init_process_group(backend="nccl", device_id=dev)
+torch.cuda.set_device(0)
+# the collectives and operand types bench.py uses between ranks, on device tensors over RCCL
+t = torch.tensor([1.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t.item()) == 1.5
+k = torch.tensor([7], dtype=torch.int64, device=dev); dist.all_reduce(k, op=dist.ReduceOp.SUM); assert int(k.item()) == 7
+c = torch.arange(5, dtype=torch.int32, device=dev); out = [torch.zeros(5, dtype=torch.int32, device=dev)]
+dist.all_gather(out, c); assert torch.equal(out[0], c)
+b = torch.arange(136, dtype=torch.uint8, device=dev); ob = [torch.zeros(136, dtype=torch.uint8, device=dev)]
+dist.all_gather(ob, b); assert torch.equal(ob[0], b)
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl one-rank ok")
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_backend_takes_the_collectives_of_the_record_gather():
+    """The rehearsal above talks over gloo (two ranks cannot share one GPU under RCCL).  What can be checked on a one-GPU box:
+    that the "nccl" (= RCCL) backend initialises with `device_id` as bench.py does and accepts the collectives and operand
+    types of the timing reductions and of shard.gather_strip_records (float64 MAX, int64 SUM, all_gather of int32 counts and
+    of uint8 record bytes) on device tensors."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, str(port)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stderr[-3000:]

@@ -282,3 +282,31 @@ def test_gray_variant_is_probed_per_image_width():
     got = {w: capi.host_gray_variant(w) for w in (1, 2, 3, 8, 17, 64, 250)}
     assert all(0 <= v <= 5 for v in got.values())
     assert capi.host_gray_variant(64) == capi.host_gray_variant()
+
+
+def test_host_pow_tables_reproduce_the_reference_histogram_and_mask(capi):
+    """_capi.host_pow_tables (the LfaHostPow record behind lfa_set_host_pow): bin(g) = the largest k with edges_g[k] <= g must
+    be the bin np.histogram gives gray ** 0.4 (exposure.py:298-301, histograms.py:800-859), and gray >= thr_g[b] must be
+    gray ** 0.4 > the centre of bin b (thresholding.py:378-381, detection.py:47) -- for EVERY gray value, including the ones
+    that sit on an edge in gamma space.  Checked on dense random grays, on the 256 grays of grey pixels and on the exact
+    tie gmax / 32 (gamma value vmax / 4 = edge 64 when gmin = 0)."""
+    from oracle import lfa_oracle as O
+    rng = np.random.default_rng(11)
+    grey = O.rgb2gray(np.arange(256, dtype=np.uint8)[:, None, None].repeat(3, axis=2))[:, 0]
+    cases = [(0.0, float(grey[128]), np.concatenate([grey[:129], [grey[128] / 32]])),
+             (float(grey[3]), float(grey[250]), grey[3:251]),
+             (0.02, 0.9, rng.uniform(0.02, 0.9, 200000)),
+             (0.3, 0.3000001, rng.uniform(0.3, 0.3000001, 5000))]
+    for gmin, gmax, g in cases:
+        g = np.ascontiguousarray(np.concatenate([g, [gmin, gmax]]))
+        tab = capi.host_pow_tables(gmin, gmax)
+        v = g ** 0.4
+        assert tab[0] == v.min() and tab[1] == v.max()
+        want_counts, centres = O.histogram_image_range(v)
+        edges_g, thr_g = tab[2:259], tab[259:]
+        bins = np.clip(np.searchsorted(edges_g, g, side="right") - 1, 0, 255)
+        assert np.array_equal(np.bincount(bins, minlength=256), want_counts)
+        for b in (0, 1, 63, 64, 128, 254):
+            assert np.array_equal(g >= thr_g[b], v > centres[b]), b
+    const = capi.host_pow_tables(0.25, 0.25)                       # all-equal image: edge 0 = gmin, everything else unreachable
+    assert const[0] == const[1] and const[2] == 0.25 and np.isinf(const[3:]).all()

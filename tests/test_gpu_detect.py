@@ -612,12 +612,16 @@ def test_random_small_images_against_oracle(capi, eng, seed):
             arr = img.astype(np.uint16)
         else:
             ch = [np.clip(img + rng.integers(-3, 4, size=(H, W)), 0, 255) for _c in range(3)]
+            if rng.random() < 0.35:                                 # three equal channels (cv2.imread of a grey file): the
+                ch = [ch[0]] * 3                                    # equal-channel mode, entered by the handle itself or forced
             arr = np.ascontiguousarray(np.stack(ch, axis=2).astype(np.uint8))
+            if rng.random() < 0.1:
+                arr[int(rng.integers(0, H)), int(rng.integers(0, W)), int(rng.integers(0, 3))] ^= 1      # ... but for one pixel
         L = int(rng.choice([1, 2, 5, 10, 10, 10, 17]))
         mm_r, mm_c = int(rng.integers(0, max(1, H))), int(rng.integers(0, max(1, W // 2 + 1)))
         # colour: default choice of the class plane, or forced; uint16: default, or one-pass histogram with the plane forced
         # (its classes centred on whatever threshold the shared handle met last), or the two-pass histogram
-        eng.set_debug_flags(int(rng.choice([0, 4])) if kind == 2 else (int(rng.choice([0, 16 | 4, 8])) if kind == 1 else 0))
+        eng.set_debug_flags(int(rng.choice([0, 4, 0, 1024, 1024 | 1])) if kind == 2 else (int(rng.choice([0, 16 | 4, 8])) if kind == 1 else 0))
         try:
             check_detect(capi, eng, arr, mm_r, mm_c, L)
         finally:

@@ -25,7 +25,7 @@ def _load(path, name):
 def run(seeds, first):
     import image_analysis_amd._capi as capi
     td = _load(os.path.join(ROOT, "tests", "test_gpu_detect.py"), "td")
-    td.ALLOW_AMBIGUOUS = True        # LfaImageInfo.ambiguous != 0 (a pixel within 2^-40 of a histogram edge) is counted, the results still checked
+    td.ALLOW_AMBIGUOUS = True        # (kept for the count; since round 3 Engine.detect re-decides such an image with the host's pow and check_detect accepts it)
     eng = capi.Engine(device=0, max_h=256, max_w=256, max_c=3, max_batch=4)
     t0 = time.time()
     strips = labels = 0
@@ -58,7 +58,7 @@ def run(seeds, first):
             print(f"seed {seed} ok, {time.time() - t0:.0f} s", flush=True)
     eng.close()
     print(f"detect fuzz ok: seeds {first}..{first + seeds - 1} ({7 * seeds} calls on one handle; the batches held {labels} labels, {strips} strips; "
-          f"{td.AMBIGUOUS_SEEN[0]} images flagged ambiguous, results equal all the same), {time.time() - t0:.0f} s")
+          f"{td.AMBIGUOUS_SEEN[0]} images flagged ambiguous and decided again with the host's pow, every one equal to the oracle), {time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
