@@ -317,23 +317,25 @@ __global__ __launch_bounds__(256) void k_roi_index(const LfaRoi* rois, int n_roi
 }
 
 // sum of the elements in bytes [b0, b0 + nbytes) of the row at `row` (16-byte aligned, LDS or global), by one lane:
-// 16-byte pieces, the first and the last masked per byte
+// 16-byte pieces, the first and the last masked per byte.  The two byte masks are built once per call as pairs of 64-bit
+// words (a shift and a select each) and applied through selects -- no branch inside the loop (round 3: the per-dword
+// min / max / shift ladder of the first version was a third of the band kernel's vector instructions).
 template <class PTR>
 __device__ __forceinline__ uint32_t lane_row_sum(PTR row, int b0, int nbytes, int esz) {
     const int a0 = b0 & ~15;
     const int nch = (((b0 + nbytes + 15) & ~15) - a0) >> 4;
+    const int lo = b0 - a0;                                           // 0..15 bytes to drop at the front of piece 0
+    const int hi = b0 + nbytes - (a0 + 16 * (nch - 1));               // 1..16 bytes to keep of the last piece
+    const unsigned long long ones = ~0ull;
+    const unsigned long long f0 = lo >= 8 ? 0ull : (ones << (8 * lo)), f1 = lo >= 8 ? (ones << (8 * (lo - 8))) : ones;
+    const unsigned long long l0 = hi >= 8 ? ones : ~(ones << (8 * hi));
+    const unsigned long long l1 = hi >= 16 ? ones : (hi > 8 ? ~(ones << (8 * (hi - 8))) : 0ull);
     uint32_t sv = 0u;
     for (int d = 0; d < nch; ++d) {
         const uint4 x = *(const uint4*)(row + a0 + 16 * d);
-        uint32_t w[4] = {x.x, x.y, x.z, x.w};
-        if (d == 0 || d == nch - 1) {
-            const int lo = b0 - (a0 + 16 * d), hi = b0 + nbytes - (a0 + 16 * d);   // keep bytes [lo, hi) of the piece
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int l = min(max(lo - 4 * k, 0), 4), h = min(max(hi - 4 * k, 0), 4);
-                w[k] &= (l >= 4 ? 0u : (0xffffffffu << (8 * l))) & (h >= 4 ? 0xffffffffu : ~(0xffffffffu << (8 * h)));
-            }
-        }
+        const unsigned long long m0 = (d == 0 ? f0 : ones) & (d == nch - 1 ? l0 : ones);
+        const unsigned long long m1 = (d == 0 ? f1 : ones) & (d == nch - 1 ? l1 : ones);
+        const uint32_t w[4] = {x.x & (uint32_t)m0, x.y & (uint32_t)(m0 >> 32), x.z & (uint32_t)m1, x.w & (uint32_t)(m1 >> 32)};
 #pragma unroll
         for (int k = 0; k < 4; ++k) sv = (esz == 1) ? __builtin_amdgcn_sad_u8(w[k], 0u, sv) : (sv + (w[k] & 0xffffu) + (w[k] >> 16));
     }
