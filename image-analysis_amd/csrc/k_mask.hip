@@ -164,8 +164,13 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
             uint32_t lo[16], hi[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) { lo[k] = 0; hi[k] = 0; }
-            const int64_t px_bytes = (MODE == 2) ? 3 : (MODE == 1 ? 2 : 1);
-            const uint8_t* p = base + ((int64_t)r0 * W + (int64_t)cg * 16) * px_bytes;
+            // Equal-channel image of a grey-mode call (k_grey_hist left channel 0 of every pixel in a byte plane): G = 10000 * b, so
+            // `G >= G_thr` is `b >= ceil(G_thr / 10000)` -- one byte per pixel read instead of three.  Integer form of the threshold only.
+            const bool grey_bytes = MODE == 2 && j.grey_plane && integer_path && j.edges_i[(int64_t)img * kEdgesI + kEdgesI_Grey] != 0u;
+            const int b_thr = (G_thr > 2550000u) ? 256 : (int)((G_thr + 9999u) / 10000u);
+            const int64_t px_bytes = grey_bytes ? 1 : ((MODE == 2) ? 3 : (MODE == 1 ? 2 : 1));
+            const uint8_t* src = grey_bytes ? j.grey_plane + (int64_t)img * j.grey_plane_stride : base;
+            const uint8_t* p = src + ((int64_t)r0 * W + (int64_t)cg * 16) * px_bytes;
             const int64_t row_bytes = (int64_t)W * px_bytes;
             // one row of 16 pixels: compare and drop the result into bit `rbit` of the 16 column words
             auto row = [&](const uint8_t* q, uint32_t (&acc)[16], uint32_t rbit) {
@@ -182,6 +187,11 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
                         const int x = (int)((w[k >> 1] >> ((k & 1) * 16)) & 0xffffu);
                         acc[k] |= (x > x_thr) ? rbit : 0u;
                     }
+                } else if (grey_bytes) {
+                    const uint4 a = *(const uint4*)q;
+                    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc[k] |= ((int)byte_of(w, k) >= b_thr) ? rbit : 0u;
                 } else {
                     uint32_t w[12];
                     load48(q, w);

@@ -348,6 +348,8 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
     j.rowsum = (uint32_t*)w.rowsum.p;
     j.rowsum_cap = 16 * H;
     j.slot_rs_off = (int32_t*)w.slot_rs_off.p;
+    j.grey_plane_stride = (int64_t)j.run_cap * 16;
+    j.grey_plane = (j.grey_mode && j.grey_plane_stride >= (int64_t)H * W && !(h->debug_flags & 4096)) ? (uint8_t*)w.bbox.p : nullptr;
     j.lut8 = (const uint8_t*)h->lut8.p;
     j.lut16 = (const uint16_t*)h->lut16.p;
     return j;
@@ -429,7 +431,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         // no events either: nothing is recorded for, or awaited from, other handles (lfa_stream_wait_passes /
         // lfa_chain_passes do not see static calls), so the call is kernels and memsets on `s` only and can be captured
         j.passes_event = nullptr; j.wait_event = nullptr;
-        j.plane_stats = nullptr; j.bins = nullptr; j.u16_plane = 0; j.hist_abs = 0; j.win_hint = 0; j.grey_mode = 0;
+        j.plane_stats = nullptr; j.bins = nullptr; j.u16_plane = 0; j.hist_abs = 0; j.win_hint = 0; j.grey_mode = 0; j.grey_plane = nullptr;
         j.u16_lds_bins = lfa::kLdsBinsU16; j.u16_pred = 0; j.u16_pa = 0; j.u16_ps = 0;
         if (ws_rois) *ws_rois = (LfaRoi*)w.rois.p;
     } else {

@@ -92,6 +92,9 @@ struct Job {
     int32_t* slot_rs_off;    // [n][max_strips] the same offset per output strip slot (written by k_finalize)
     int32_t grey_mode;       // colour uint8 images are expected to have three equal channels (what cv2.imread makes of a grey file):
                              //         k_grey_hist takes their byte histogram in ONE pass and k_minmax_rgb / k_hist_rgb skip them
+    uint8_t* grey_plane;     // grey mode: [n][grey_plane_stride] channel 0 of every pixel, written by k_grey_hist and compared by k_mask instead of
+    int64_t grey_plane_stride;   //         the three channels (1 byte per pixel instead of 3).  Lives in the `bbox` buffer, which nothing uses before
+                             //         the labelling stage; null when that buffer is smaller than H*W bytes per image (line_length > 15)
     const double* host_pow;  // [n] LfaHostPow records (lfa_set_host_pow) or null: vmin, vmax, 257 gray-space edges, 256 gray-space thresholds
     const uint8_t* lut8;     // [256]
     const uint16_t* lut16;   // [65536]

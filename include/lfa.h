@@ -187,7 +187,8 @@ int lfa_set_host_pow(LfaHandle h, const LfaHostPow* tables, int n);
  * never.  By default a handle takes it once at least half of the colour images of its last completed call had three equal
  * channels in every pixel -- what cv2.imread hands the reference for a grey file (detection.py:454): one pass then takes the
  * byte histogram and the min/max and histogram passes skip the image; an image with a single unequal pixel takes the
- * ordinary passes.  Results are identical either way.
+ * ordinary passes.  bit12 (4096): the equal-channel pass writes no byte plane (the mask pass then compares the three
+ * channels, as it does for any image without a class plane).  Results are identical either way.
  * bit8 (256) / bit9 (512): k_edges_rgb moves every interior gray-space histogram edge it computed one double up / down --
  * what a pow() whose last bit differs would do -- so that the tests can show an image with a pixel exactly on an edge
  * going wrong without lfa_set_host_pow and right with it (tables from lfa_set_host_pow are never touched). */

@@ -621,7 +621,7 @@ def test_random_small_images_against_oracle(capi, eng, seed):
         mm_r, mm_c = int(rng.integers(0, max(1, H))), int(rng.integers(0, max(1, W // 2 + 1)))
         # colour: default choice of the class plane, or forced; uint16: default, or one-pass histogram with the plane forced
         # (its classes centred on whatever threshold the shared handle met last), or the two-pass histogram
-        eng.set_debug_flags(int(rng.choice([0, 4, 0, 1024, 1024 | 1])) if kind == 2 else (int(rng.choice([0, 16 | 4, 8])) if kind == 1 else 0))
+        eng.set_debug_flags(int(rng.choice([0, 4, 0, 1024, 1024 | 1, 1024 | 4096])) if kind == 2 else (int(rng.choice([0, 16 | 4, 8])) if kind == 1 else 0))
         try:
             check_detect(capi, eng, arr, mm_r, mm_c, L)
         finally:
@@ -789,9 +789,16 @@ def test_equal_channel_images_take_one_pass_and_match_the_oracle(capi, golden_di
     mm_r, mm_c = gui_params(grey)
     e = capi.Engine(device=0, max_h=H, max_w=W, max_batch=len(imgs))
     try:
-        for flags in (1024, 1024 | 1, 1024 | 4):
+        # (1: float64 compare path; 4: class plane forced for the images that fall back; 4096: no byte plane for the mask pass;
+        #  line_length 17: the byte plane's home, the bbox buffer, is then smaller than the image and the plane is left out)
+        for flags, L in ((1024, 10), (1024 | 1, 10), (1024 | 4, 10), (1024 | 4096, 10), (1024, 17), (1024, 3)):
             e.set_debug_flags(flags)
             for i, im in enumerate(imgs):                     # one by one: the debug fetches look at the last call
+                check_detect(capi, e, im, mm_r, mm_c, L)
+                assert e.debug_grey_path(0) == (i in (0, 3, 4)), (flags, i)
+            if L != 10:
+                continue
+            for i, im in enumerate(imgs):
                 check_detect(capi, e, im, mm_r, mm_c)
                 assert e.debug_grey_path(0) == (i in (0, 3, 4)), (flags, i)
             res = e.detect(np.stack(imgs), mm_r, mm_c)
