@@ -284,8 +284,12 @@ __global__ __launch_bounds__(64) void k_finalize(Job j, OutPtrs o) {
 }
 
 hipError_t launch_regions(const Job& j, const OutPtrs& o, hipStream_t s) {
-    int gx = (8192 + j.n - 1) / j.n;                       // one block per candidate; blocks loop when there are more
-    if (gx < 16) gx = 16;
+    // one block per candidate, blocks loop when there are more.  Almost every call needs no box sum at all (the kernel's blocks
+    // return at once unless pixel (0,0) of their image is foreground), and then the launch costs what its blocks take to be
+    // dispatched through a chip that is busy with another lane's image pass: 8192 blocks 130 us, in the lane's serial chain
+    // (kernel timeline of configs[2], round 3) -- so about a thousand blocks, not eight
+    int gx = (1024 + j.n - 1) / j.n;
+    if (gx < 2) gx = 2;
     if (gx > 256) gx = 256;
     LFA_LAUNCH("k_box_sums", k_box_sums, dim3(gx, j.n), dim3(256), 0, s, j);
     const size_t fin_lds = (size_t)2 * (j.max_strips < kMaxStripsLds ? j.max_strips : kMaxStripsLds) * sizeof(Acc);

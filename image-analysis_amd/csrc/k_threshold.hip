@@ -1014,6 +1014,12 @@ int hist_rgb_capacity() {
 
 hipError_t launch_threshold(const Job& j, hipStream_t s) {
     LFA_LAUNCH("k_init_info", k_init_info, dim3(j.H >= 4096 ? 8 : 2, j.n), dim3(256), 0, s, j);
+    if (j.C == 1 && j.dtype == LFA_U16 && j.hist_abs) {
+        // one-pass uint16 histogram: bins = pixel values, every bin may be touched.  Cleared BEFORE the wait below: it depends on
+        // nothing of the other lane (round 3: behind the wait its 27 us sat between two lanes' histogram passes, in every chunk)
+        const hipError_t e = hipMemsetAsync(j.hist, 0, (size_t)j.n * kHistBinsU16 * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+    }
     if (j.wait_event) {                                   // lfa_chain_passes: the passes below start when the other handle's are done
         const hipError_t e = hipStreamWaitEvent(s, j.wait_event, 0);
         if (e != hipSuccess) return e;
@@ -1043,11 +1049,7 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
         if (j.passes_event) (void)hipEventRecord(j.passes_event, s);
         LFA_LAUNCH("k_otsu_int", k_otsu_int, dim3(j.n), dim3(256), 0, s, j);
     } else {
-        if (j.hist_abs) {
-            // one pass: bins = pixel values, the range falls out of the histogram (k_otsu_int)
-            const hipError_t e = hipMemsetAsync(j.hist, 0, (size_t)j.n * kHistBinsU16 * sizeof(uint32_t), s);
-            if (e != hipSuccess) return e;
-        } else {
+        if (!j.hist_abs) {                                // (one pass: bins = pixel values, cleared above; the range falls out of the histogram, k_otsu_int)
             const dim3 grid(blocks_per_image(j, 256 * 64), j.n);
             LFA_LAUNCH("k_minmax_u16", k_minmax_u16, grid, dim3(256), 0, s, j);
             LFA_LAUNCH("k_zero_hist_u16", k_zero_hist_u16, dim3(16, j.n), dim3(256), 0, s, j);
