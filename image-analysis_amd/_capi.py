@@ -737,6 +737,13 @@ class Engine:
         _check(lib.lfa_debug_fetch(self._h, image_index, DBG_PLANE, out.data_ptr(), 4, current_stream_ptr(self.device)))
         return bool(out.cpu().numpy()[0])
 
+    def debug_pred_path(self, image_index):
+        """True if the mask of image `image_index` of the last call came from the predicted-threshold bit plane (LFA_DBG_PLANE == 2)."""
+        torch = _torch()
+        out = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _check(lib.lfa_debug_fetch(self._h, image_index, DBG_PLANE, out.data_ptr(), 4, current_stream_ptr(self.device)))
+        return int(out.cpu().numpy()[0]) == 2
+
     def debug_grey_path(self, image_index):
         """True if image `image_index` of the last call went through the equal-channel path (LFA_DBG_GREY)."""
         torch = _torch()

@@ -18,8 +18,47 @@ __device__ __forceinline__ uint2 nt_load8(const uint8_t* p) {   // read once, by
 }
 
 
+// 8 x 8 bit matrix in two dwords (byte i = row i, bit k = column k; lo = rows 0-3): transposed in place, so that byte k
+// holds column k with bit i = row i.  Three delta swaps; the first two stay inside a dword, the last one crosses.
+__device__ __forceinline__ void transpose_bits8x8(uint32_t& lo, uint32_t& hi) {
+    uint32_t t;
+    t = (lo ^ (lo >> 7)) & 0x00aa00aau; lo ^= t ^ (t << 7);
+    t = (hi ^ (hi >> 7)) & 0x00aa00aau; hi ^= t ^ (t << 7);
+    t = (lo ^ (lo >> 14)) & 0x0000ccccu; lo ^= t ^ (t << 14);
+    t = (hi ^ (hi >> 14)) & 0x0000ccccu; hi ^= t ^ (t << 14);
+    t = (lo ^ (hi << 4)) & 0xf0f0f0f0u; lo ^= t; hi ^= t >> 4;
+}
+
+// Predicted-threshold mode, after k_mask: the pixels of the listed groups that lie inside the window (those the bit plane
+// left clear without knowing) get the exact compare against the image's threshold and are ORed into the words k_mask
+// stored.  Grid (blocks, n); almost always a handful of entries per image.
+__global__ __launch_bounds__(256) void k_mask_fix(Job j) {
+    const int img = blockIdx.y;
+    const uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
+    if (eg[kEdgesI_Bins] != 2u) return;
+    const uint32_t n = min(eg[kEdgesI_PredCnt], (uint32_t)j.pred_cap);
+    const uint32_t G_thr = eg[kEdgesI_MaskThr], t_lo = j.pred_lo, t_hi = j.pred_hi;
+    const uint32_t* list = j.pred_list + (int64_t)img * j.pred_stride;
+    const uint8_t* base = j.images + (int64_t)img * j.img_bytes;
+    uint64_t* out = j.maskT + (int64_t)img * j.HB * j.W;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const int64_t p0 = (int64_t)list[e] * 16;                         // W % 16 == 0: a group never crosses a row
+        const int r = (int)(p0 / j.W), c0 = (int)(p0 % j.W);
+        uint32_t w[12];
+        load48(base + p0 * 3, w);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t G = gray_G16(w, k);
+            if (G >= t_lo && G < t_hi && G >= G_thr)
+                atomicOr((unsigned long long*)&out[(int64_t)(r >> 6) * j.W + c0 + k], 1ull << (r & 63));
+        }
+    }
+}
+
 // MODE 0: uint8 2-D, 1: uint16 2-D, 2: uint8 colour.  VEC: 16 pixels per lane per row through 16-byte loads.
-template <int MODE, int V, bool VEC>
+// PRED: a call in predicted-threshold mode (bit plane or the image itself; a kernel of its own, so that its registers do
+// not weigh on the class-plane path).
+template <int MODE, int V, bool VEC, bool PRED = false>
 __global__ __launch_bounds__(256) void k_mask(Job j) {
     const int img = blockIdx.y;
     const LfaImageInfo inf = j.info[img];
@@ -41,7 +80,66 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
             G_thr = eg[kEdgesI_MaskThr];
             integer_path = eg[kEdgesI_MaskCrit] == 0;
         }
-        if (VEC && j.bins && eg[kEdgesI_Bins]) {
+        if (PRED && VEC && MODE == 2 && j.bins && eg[kEdgesI_Bins] == 2u) {
+            // Predicted-threshold bit plane (Job::pred_mode): bit = G >= pred_hi, row-major, 16 pixels = one 16-bit word.  The
+            // image's threshold lies inside the window, so a set bit is a set pixel and a clear bit a clear pixel except for
+            // the listed pixels inside the window, which k_mask_fix ORs in afterwards.  What remains here is turning 64 rows
+            // x 16 columns of bits into 16 vertical words: 8 x 8 bit blocks, transposed by three delta swaps each.
+            const int ncg = W >> 4;
+            const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+            if (item >= (int64_t)j.HB * ncg) return;
+            const int rb = (int)(item / ncg), cg = (int)(item % ncg);
+            const int r0 = rb * 64;
+            const int rows = min(64, H - r0);
+            const int64_t rowb = (int64_t)W >> 3;
+            const uint8_t* bp = j.bins + (int64_t)img * (((int64_t)H * W) >> 3) + (int64_t)r0 * rowb + (int64_t)cg * 2;
+            uint32_t rw[64];
+            if (__all(rows == 64)) {                                      // (all but the image's last row block: no lane masks the loads)
+#pragma unroll
+                for (int i = 0; i < 64; ++i)                              // all 64 rows are requested together
+                    rw[i] = (uint32_t)__builtin_nontemporal_load((const uint16_t*)(bp + (int64_t)i * rowb));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 64; ++i)
+                    rw[i] = (i < rows) ? (uint32_t)__builtin_nontemporal_load((const uint16_t*)(bp + (int64_t)i * rowb)) : 0u;
+            }
+            uint32_t Ta[8][2], Tb[8][2];                                  // [row byte jb][low / high dword]: columns 0-7 / 8-15
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb) {
+                const uint32_t* q = rw + jb * 8;
+                // byte i of the 64-bit matrix = bits of row 8jb+i: columns 0-7 (byte 0 of the row word) or 8-15 (byte 1)
+                const uint32_t a01 = __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0400u), a23 = __builtin_amdgcn_perm(q[3], q[2], 0x0c0c0400u);
+                const uint32_t a45 = __builtin_amdgcn_perm(q[5], q[4], 0x0c0c0400u), a67 = __builtin_amdgcn_perm(q[7], q[6], 0x0c0c0400u);
+                const uint32_t b01 = __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0501u), b23 = __builtin_amdgcn_perm(q[3], q[2], 0x0c0c0501u);
+                const uint32_t b45 = __builtin_amdgcn_perm(q[5], q[4], 0x0c0c0501u), b67 = __builtin_amdgcn_perm(q[7], q[6], 0x0c0c0501u);
+                Ta[jb][0] = __builtin_amdgcn_perm(a23, a01, 0x05040100u); Ta[jb][1] = __builtin_amdgcn_perm(a67, a45, 0x05040100u);
+                Tb[jb][0] = __builtin_amdgcn_perm(b23, b01, 0x05040100u); Tb[jb][1] = __builtin_amdgcn_perm(b67, b45, 0x05040100u);
+                transpose_bits8x8(Ta[jb][0], Ta[jb][1]);
+                transpose_bits8x8(Tb[jb][0], Tb[jb][1]);                  // now byte k = column k (+8), bit i = row 8jb+i
+            }
+            uint64_t* o = out + (int64_t)rb * W + cg * 16;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                uint32_t lo2[2], hi2[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int kk = k + e, half = (kk & 7) >> 2, m = kk & 3;
+                    const uint32_t sel = (uint32_t)(((4 + m) << 8) | m);            // byte0 = second operand's byte m, byte1 = first's
+                    uint32_t b8[8];
+#pragma unroll
+                    for (int jb = 0; jb < 8; ++jb) b8[jb] = (kk < 8) ? Ta[jb][half] : Tb[jb][half];
+                    const uint32_t p01 = __builtin_amdgcn_perm(b8[1], b8[0], sel), p23 = __builtin_amdgcn_perm(b8[3], b8[2], sel);
+                    const uint32_t p45 = __builtin_amdgcn_perm(b8[5], b8[4], sel), p67 = __builtin_amdgcn_perm(b8[7], b8[6], sel);
+                    lo2[e] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                    hi2[e] = __builtin_amdgcn_perm(p67, p45, 0x05040100u);
+                }
+                uint4 v;
+                v.x = lo2[0]; v.y = hi2[0]; v.z = lo2[1]; v.w = hi2[1];
+                *(uint4*)(o + k) = v;
+            }
+            return;
+        }
+        if (!PRED && VEC && j.bins && eg[kEdgesI_Bins] == 1u) {
             // The class plane k_hist_rgb wrote (bin >> 4 of every pixel, 4 bits each) decides every pixel whose class
             // differs from the class q of the Otsu bin: class > q: set, class < q: clear -- half a byte per pixel
             // instead of three.  A pixel of class q is settled by the exact compare on the image itself.
@@ -256,7 +354,12 @@ static void launch_mode(const Job& j, hipStream_t s) {
     const bool vec = j.aligned16 && (j.W % 16 == 0);
     if (vec) {
         const int64_t items = (int64_t)j.HB * (j.W >> 4);
-        LFA_LAUNCH("k_mask", (k_mask<MODE, V, true>), dim3((unsigned)((items + 255) / 256), j.n), dim3(256), 0, s, j);
+        if (MODE == 2 && j.pred_mode) {
+            LFA_LAUNCH("k_mask", (k_mask<MODE, V, true, true>), dim3((unsigned)((items + 255) / 256), j.n), dim3(256), 0, s, j);
+            LFA_LAUNCH("k_mask_fix", k_mask_fix, dim3(4, j.n), dim3(256), 0, s, j);
+        } else {
+            LFA_LAUNCH("k_mask", (k_mask<MODE, V, true>), dim3((unsigned)((items + 255) / 256), j.n), dim3(256), 0, s, j);
+        }
     } else {
         const int64_t items = (int64_t)j.HB * j.W;
         LFA_LAUNCH("k_mask_scalar", (k_mask<MODE, V, false>), dim3((unsigned)((items + 255) / 256), j.n), dim3(256), 0, s, j);

@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void k_init_info(Job j) {
         z.n_runs = 0; z.n_labels = 0; z.label00 = 0; z.n_candidates = 0; z.n_accepted = 0; z.n_strips = 0; z.status = 0;
         j.info[img] = z;
         j.edges_i[(int64_t)img * kEdgesI + kEdgesI_Grey] = (j.C == 3 && j.dtype == LFA_U8 && j.aligned16) ? 1u : 0u;
+        j.edges_i[(int64_t)img * kEdgesI + kEdgesI_PredCnt] = 0u;
     }
     if (j.hist_stride == 256) {
         uint32_t* gh = j.hist + (int64_t)img * 256;
@@ -590,9 +591,12 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     __shared__ uint32_t sg[kEdges + 3];
     // integer path: one table entry per bucket of 1024 G values (G <= 2 550 000 < 2^22):
     //   .x      the next edge above the bucket's first G (clamped to 2^22-1 = never reached)
-    //   .y      bits 0-7 the bin of the bucket's first G; bit 31: a second edge lies inside the bucket as well (only for
-    //           nearly black pixels, where bins are narrower than a bucket) -> that pixel walks the edge list
-    // Two words, so that neither has to be taken apart: bin = .y + (G >= .x) is a compare and an add-with-carry.
+    //   .y      bits 0-7 the bin of the bucket's first G; bit 30: a second edge lies inside the bucket as well (only for
+    //           nearly black pixels, where bins are narrower than a bucket) -> that pixel walks the edge list;
+    //           predicted-threshold mode (Job::pred_mode; the window's ends are multiples of 1024): bit 31 the bucket lies at or
+    //           above the window, bit 29 inside it
+    // Two words, so that neither has to be taken apart: bin = .y + (G >= .x) is a compare and an add-with-carry; the flag bits
+    // ride along in the sum, and the LDS index (bin * 16, 32-bit) drops them by itself.
     __shared__ uint2 tab[2496];
     __shared__ lfa_u32x4 turn[4][192];
     if (integer_path) {
@@ -609,15 +613,16 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
                 hi = ge ? hi : mid - 1;
             }
             const uint32_t e1 = sg[lo + 1] < 0x3fffffu ? sg[lo + 1] : 0x3fffffu;
-            const uint32_t two = (sg[lo + 2] <= G0 + 1023u) ? 0x80000000u : 0u;
-            tab[b] = make_uint2(e1, (uint32_t)lo | two);
+            const uint32_t two = (sg[lo + 2] <= G0 + 1023u) ? 0x40000000u : 0u;
+            const uint32_t win = !j.pred_mode ? 0u : (G0 >= j.pred_hi ? 0x80000000u : (G0 >= j.pred_lo ? 0x20000000u : 0u));
+            tab[b] = make_uint2(e1, (uint32_t)lo | two | win);
         }
         __syncthreads();
     }
     auto binG = [&](uint32_t G, uint32_t& flags) -> uint32_t {   // bin unless the bucket is flagged (then a lower bound)
         const uint2 ent = tab[G >> 10];                       // one 8-byte LDS read
         flags |= ent.y;
-        return ent.y + ((G >= ent.x) ? 1u : 0u);              // bit 31 rides along: no user looks above bit 7 without masking
+        return ent.y + ((G >= ent.x) ? 1u : 0u);              // bits 29-31 ride along: no user looks above bit 7 without masking
     };
     auto walk = [&](uint32_t G, uint32_t k) -> uint32_t { k &= 0xffu; while (G >= sg[k + 1]) ++k; return k; };   // sg[256..] = inf ends it
     // class plane for k_mask (integer path only): bin >> 4 of every pixel, two pixels per byte (pixel 2q in the low nibble)
@@ -655,8 +660,15 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
                 const int64_t i = (int64_t)r * 192 + 64 * k + lane;
                 return base + (i < n16 ? i : (int64_t)r * 192) * 16;
             };
-            auto pass = [&](auto plane) {
-                constexpr bool kPlane = decltype(plane)::value;
+            // kind 0: histogram only; 1: also the 4-bit class plane; 2: also the predicted-threshold bit plane and the list of
+            // undecided groups (Job::pred_mode)
+            uint8_t* pbits = j.bins + (int64_t)img * (npix >> 3);
+            uint32_t* pcnt = j.edges_i + (int64_t)img * kEdgesI + kEdgesI_PredCnt;
+            uint32_t* plist = j.pred_list + (int64_t)img * j.pred_stride;
+            const uint32_t pcap = (uint32_t)j.pred_cap;
+            auto pass = [&](auto kind) {
+                constexpr int kKind = decltype(kind)::value;
+                constexpr bool kPlane = kKind != 0;
                 Raw48 nx;
                 int r = (int)blockIdx.x * per_block + wv4;
                 if (r >= r_end) return;
@@ -676,20 +688,49 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
                     uint32_t G[16], kb[16], flags = 0;
 #pragma unroll
                     for (int k = 0; k < 16; ++k) { G[k] = gray_G16(w, k); kb[k] = binG(G[k], flags); }
-                    if ((int)flags < 0) {                             // some pixel of the group is in a two-edge bucket
+                    uint32_t set = 0;
+                    if (kKind == 2) {
+                        // bit k of `set`: pixel k lies at or above the window (set whatever the threshold turns out to be, as long
+                        // as it is inside the window): bit 31 of the table word, shifted in by one v_alignbit per pixel
+#pragma unroll
+                        for (int k = 15; k >= 0; --k) set = __builtin_amdgcn_alignbit(set, kb[k], 31);
+                    }
+                    if (flags & 0x40000000u) {                        // some pixel of the group is in a two-edge bucket
 #pragma unroll
                         for (int k = 0; k < 16; ++k) kb[k] = walk(G[k], kb[k]);
                     }
-                    if (g < ng) {                                     // only the image's last round has lanes past the end; every round has
+                    if (kKind == 2) {
+                        // a group with a pixel in a bucket inside the window goes on the image's list: k_mask_fix decides its
+                        // pixels once the threshold is known
+                        const bool und = (flags & 0x20000000u) != 0u && g < ng;
+                        const unsigned long long um = __ballot(und);
+                        if (um) {                                     // rare: the valley of the histogram
+                            const int leader = __ffsll(um) - 1;
+                            uint32_t slot0 = 0;
+                            if (lane == leader) slot0 = atomicAdd(pcnt, (uint32_t)__popcll(um));
+                            slot0 = (uint32_t)__shfl((int)slot0, leader);
+                            const uint32_t slot = slot0 + (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
+                            if (und && slot < pcap) plist[slot] = (uint32_t)g;
+                        }
+                        if (g < ng) {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) hadd(kb[k]);
+                            vm_store2(pbits + g * 2, set);
+                        }
+                    } else if (g < ng) {                              // only the image's last round has lanes past the end; every round has
                         uint32_t pk[2] = {0u, 0u};                    // lane 0 inside, so the store below is one operation of the wave in
 #pragma unroll                                                        // every round -- the hand-counted vmcnt waits rely on that
                         for (int k = 0; k < 16; ++k) { hadd(kb[k]); pk[k >> 3] |= ((kb[k] >> 4) & 15u) << (4 * (k & 7)); }
                         if (kPlane) vm_store8(bins + g * 8, pk[0], pk[1]);
                     }
-                    vm_wait48<kPlane ? 1 : 0>(nx);                    // the requested bytes are in; this round's store may still be on its way
+                    // the requested bytes are in; this round's store -- the newest operation, whatever the list took -- may
+                    // still be on its way
+                    vm_wait48<kPlane ? 1 : 0>(nx);
                 }
             };
-            if (bins) pass(std::true_type{}); else pass(std::false_type{});
+            if (j.pred_mode) pass(std::integral_constant<int, 2>{});
+            else if (bins) pass(std::integral_constant<int, 1>{});
+            else pass(std::integral_constant<int, 0>{});
             done = ng << 4;
         }
         for (int64_t p = done + tid; p < npix; p += nth) {
@@ -976,6 +1017,16 @@ __global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
     const bool could = few && eg[kEdgesI_Crit] == 0 && !crit && !(j.debug_flags & 1) && e_lo <= G_thr && G_thr <= e_hi;
     eg[kEdgesI_Bins] = (j.bins && could && !(j.grey_mode && is_grey)) ? 1u : 0u;      // (grey mode: no histogram pass, no plane)
     if (j.plane_stats) { if (could) atomicAdd(&j.plane_stats[0], 1u); atomicAdd(&j.plane_stats[1], 1u); }
+    // Predicted-threshold mode: the bit plane decides this image iff its threshold has an exact integer form inside the window the
+    // plane was written for and the list of undecided groups holds them all.  Every call reports the range of its integer
+    // thresholds: the next call's window (lfa_api.hip).
+    const bool exact = eg[kEdgesI_Crit] == 0 && !crit && !(j.debug_flags & 1) && j.dtype == LFA_U8 && G_thr < 0x400000u;
+    if (exact && j.plane_stats) { atomicMax(&j.plane_stats[12], 0x7fffffffu - G_thr); atomicMax(&j.plane_stats[13], G_thr); }
+    if (j.pred_mode) {
+        const bool held = exact && G_thr >= j.pred_lo && G_thr <= j.pred_hi && eg[kEdgesI_PredCnt] <= (uint32_t)j.pred_cap;
+        eg[kEdgesI_Bins] = held ? 2u : 0u;
+        if (j.plane_stats) { atomicAdd(&j.plane_stats[14], 1u); if (held) atomicAdd(&j.plane_stats[15], 1u); }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -157,6 +158,12 @@ struct LfaContext {
     // sample looks and coloured elsewhere -- the handle stays out of the mode for the next four calls.
     bool grey_on = false, pending_grey = false;
     int grey_backoff = 0;
+    // Predicted-threshold mode (Job::pred_mode): the window is the range of the integer mask thresholds of the last completed call,
+    // widened by 16384 (of G's 2 550 000 steps: a grey level and a half, about one histogram bin in mid-range) on either side.  When fewer than half of the images of a call in
+    // the mode could use their bit plane (another scene, or too many pixels inside the window), the next eight calls go without.
+    bool pred_have = false, pending_pred = false;
+    uint32_t pred_lo = 0, pred_hi = 0;
+    int pred_backoff = 0;
     // uint16 images: the histogram pass needs no min/max pass before it when the bins are the pixel values themselves (one
     // pass less over the image); worth it while the values stay below the LDS table of k_hist_u16 (camera data of 12-14
     // bits).  Chosen from the largest value of the last completed uint16 call, which travels with the counters above.
@@ -325,7 +332,21 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
     }
     j.grey_mode = (C == 3 && dtype == LFA_U8 && j.aligned16 && !(h->debug_flags & 2048) && (h->grey_on || (h->debug_flags & 1024))) ? 1 : 0;
     const bool rgb_plane = C == 3 && dtype == LFA_U8 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4));
-    j.bins = (j.u16_plane || rgb_plane) ? (uint8_t*)w.bins.p : nullptr;
+    // predicted-threshold bit plane instead of the class plane (debug flag 8192: never; 32768: always, with a window that holds every
+    // threshold and a list that holds every group -- each pixel then goes through k_mask_fix)
+    const bool pred_shape = C == 3 && dtype == LFA_U8 && j.aligned16 && (W % 16) == 0 && !j.grey_mode && !(h->debug_flags & (2 | 8192)) &&
+                            w.bins.bytes >= (size_t)n * (((size_t)H * W + 1) / 2);
+    const int64_t groups = (int64_t)H * W / 16, room = (int64_t)j.run_cap * 4;     // (the list's home holds 16 bytes per run slot)
+    if (pred_shape && (h->debug_flags & 32768)) {
+        j.pred_mode = 1; j.pred_lo = 0u; j.pred_hi = 0x400000u;
+        j.pred_cap = (int32_t)(groups < room ? groups : room);
+    } else if (pred_shape && h->pred_have && h->pred_backoff == 0) {
+        j.pred_mode = 1; j.pred_lo = h->pred_lo & ~1023u; j.pred_hi = (h->pred_hi + 1023u) & ~1023u;      // whole buckets of k_hist_rgb's table
+        j.pred_cap = (int32_t)(groups / 16 < room ? groups / 16 : room);
+    }
+    j.pred_list = (uint32_t*)w.bbox.p;
+    j.pred_stride = room;
+    j.bins = (j.u16_plane || rgb_plane || j.pred_mode) ? (uint8_t*)w.bins.p : nullptr;
     j.maskT = (uint64_t*)w.maskT.p;
     j.col_cnt = (uint32_t*)w.col_cnt.p;
     j.run_tmp = (uint32_t*)w.run_tmp.p;
@@ -409,6 +430,17 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
             else if (h->grey_backoff > 0) --h->grey_backoff;
             h->grey_on = mostly && h->grey_backoff == 0;
         }
+        {
+            const uint32_t tmin = 0x7fffffffu - h->plane_host[12], tmax = h->plane_host[13];
+            h->pred_have = h->plane_host[12] != 0u && tmin <= tmax;
+            if (h->pred_have) {
+                const uint32_t margin = (h->debug_flags & 16384) ? 0u : 16384u;
+                h->pred_lo = tmin > margin ? tmin - margin : 0u;
+                h->pred_hi = tmax + margin;
+            }
+            if (h->pending_pred && h->plane_host[14] && 2u * h->plane_host[15] < h->plane_host[14]) h->pred_backoff = 8;
+            else if (h->pred_backoff > 0) --h->pred_backoff;
+        }
         if (h->plane_host[3]) { h->u16_max = (int)h->plane_host[2]; h->u16_one_pass = h->plane_host[2] < (uint32_t)lfa::kLdsBinsU16; }
         if (h->plane_host[4]) h->win_hint = (int)h->plane_host[4];
         if (h->plane_host[8]) {
@@ -431,6 +463,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         // no events either: nothing is recorded for, or awaited from, other handles (lfa_stream_wait_passes /
         // lfa_chain_passes do not see static calls), so the call is kernels and memsets on `s` only and can be captured
         j.passes_event = nullptr; j.wait_event = nullptr;
+        j.pred_mode = 0; j.pred_list = nullptr;
         j.plane_stats = nullptr; j.bins = nullptr; j.u16_plane = 0; j.hist_abs = 0; j.win_hint = 0; j.grey_mode = 0; j.grey_plane = nullptr;
         j.u16_lds_bins = lfa::kLdsBinsU16; j.u16_pred = 0; j.u16_pa = 0; j.u16_ps = 0;
         if (ws_rois) *ws_rois = (LfaRoi*)w.rois.p;
@@ -455,6 +488,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         LFA_HIP(hipMemcpyAsync(h->plane_host, h->plane_stats.p, lfa::kStatsWords * 4, hipMemcpyDeviceToHost, s));
         h->pending_had_pred = h->u16_have_pred;
         h->pending_grey = j.grey_mode != 0;
+        h->pending_pred = j.pred_mode != 0;
         LFA_HIP(hipEventRecord(h->plane_event, s));
         h->plane_pending = true;
     }
@@ -483,6 +517,7 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
     LfaContext* h = new (std::nothrow) LfaContext();
     if (!h) return fail(LFA_ERR_NOMEM, "out of host memory");
     h->device = device; h->max_h = max_h; h->max_w = max_w; h->max_c = max_c; h->max_batch = max_batch;
+    if (const char* e = getenv("LFA_DEBUG_FLAGS")) h->debug_flags = atoi(e);      // A/B runs of unmodified programs (lfa_set_debug_flags overrides)
     int rc;
     if ((rc = ensure(h->lut8, 256)) || (rc = ensure(h->lut16, 65536 * 2))) { lfa_destroy(h); return rc; }
     // default tables from the C library's pow(); the Python binding overrides them with numpy's

@@ -118,6 +118,9 @@ __device__ __forceinline__ void vm_store8(void* p, uint32_t lo, uint32_t hi) {  
     const uint2 v = make_uint2(lo, hi);
     asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
 }
+__device__ __forceinline__ void vm_store2(void* p, uint32_t v) {                              // 1 operation (low 16 bits of v)
+    asm volatile("global_store_short %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void vm_store16(void* p, const lfa_u32x4& v) {                     // 1 operation
     asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
 }

@@ -189,9 +189,19 @@ int lfa_set_host_pow(LfaHandle h, const LfaHostPow* tables, int n);
  * byte histogram and the min/max and histogram passes skip the image; an image with a single unequal pixel takes the
  * ordinary passes.  bit12 (4096): the equal-channel pass writes no byte plane (the mask pass then compares the three
  * channels, as it does for any image without a class plane).  Results are identical either way.
+ * bit13 (8192): colour uint8 calls never take the predicted-threshold mode; bit15 (32768): always, with a window that holds
+ * every threshold, so that every pixel is decided by the exact compare of the fix-up kernel; bit14 (16384): the window is
+ * the bare range of the last call's thresholds, without a margin.  By default a handle that has completed a colour uint8
+ * call expects the next call's integer mask thresholds inside the range the last call's had (widened by 16384 of G's
+ * 2 550 000 steps, i.e. a grey level and a half, either way): the histogram pass then writes one bit per pixel -- at or above the window
+ * -- instead of the 4-bit class, and lists the 16-pixel groups holding a pixel inside the window; an image whose threshold
+ * falls inside the window, with at most 1/16 of its groups listed, takes its mask from those bits plus an exact compare of
+ * the listed pixels, any other image is compared on the image itself; a handle leaves the mode for eight calls when fewer
+ * than half of a call's images could use their bits.  Results are identical either way.
  * bit8 (256) / bit9 (512): k_edges_rgb moves every interior gray-space histogram edge it computed one double up / down --
  * what a pow() whose last bit differs would do -- so that the tests can show an image with a pixel exactly on an edge
  * going wrong without lfa_set_host_pow and right with it (tables from lfa_set_host_pow are never touched). */
+/* (The environment variable LFA_DEBUG_FLAGS, read by lfa_create, gives a new handle its initial flags.) */
 int lfa_set_debug_flags(LfaHandle h, int flags);
 
 /* ---- detect: detect_lateral_flow_tests(image, line_length) -- detection.py:31-94 ----------------------------------- */
@@ -356,7 +366,8 @@ int lfa_lines_debug_fetch(LfaHandle h, int image_index, int what, void* out, int
 #define LFA_DBG_LABELS  2   /* int32 H*W : label(dilated)                     (detection.py:66) */
 #define LFA_DBG_TABLE   3   /* int32 K*5 : minr,minc,maxr,maxc,area per label (regionprops, detection.py:71-73) */
 #define LFA_DBG_HIST    4   /* uint32 nb : histogram counts (nb = 256 colour / uint8, xmax-xmin+1 uint16; input domain) */
-#define LFA_DBG_PLANE   5   /* int32 1   : 1 if the mask of this image was decided from the class plane, else 0           */
+#define LFA_DBG_PLANE   5   /* int32 1   : 1 if the mask of this image was decided from the class plane, 2 if from the
+                                            predicted-threshold bit plane, else 0                                              */
 #define LFA_DBG_GREY    7   /* int32 1   : 1 if this colour image went through the equal-channel path (byte histogram, no min/max
                                               and no histogram pass), else 0 */
 #define LFA_DBG_ONEPASS 6   /* int32 1   : 1 if the last call took the one-pass uint16 histogram (no min/max pass), else 0 */

@@ -203,8 +203,9 @@ def test_class_plane_is_chosen_per_image_and_per_call(capi):
     Every intermediate is checked against the oracle whichever way the choice goes."""
     rng = np.random.default_rng(99)
     eng = capi.Engine(device=0, max_h=192, max_w=256, max_batch=4)
-    eng.set_debug_flags(2048)            # (these images have three equal channels: keep the handle out of the equal-channel mode,
-                                         #  which needs no class plane -- this test is about the plane)
+    eng.set_debug_flags(2048 | 8192)     # (these images have three equal channels: keep the handle out of the equal-channel mode,
+                                         #  which needs no class plane, and out of the predicted-threshold mode, which writes another
+                                         #  plane -- this test is about the class plane)
     try:
         valley = np.stack([_valley_image(rng) for _ in range(4)])
         photo = np.stack([_photo_image(rng) for _ in range(4)])
@@ -220,7 +221,7 @@ def test_class_plane_is_chosen_per_image_and_per_call(capi):
         assert run(photo) == [False] * 4                            # 3 of 4 could before: plane still written, nobody uses it
         assert run(valley) == [False] * 4                           # last call: 0 of 4 could -> this call wrote no plane
         assert run(valley) == [True] * 4                            # last call: 4 of 4 could have -> plane back on
-        eng.set_debug_flags(4 | 2048)
+        eng.set_debug_flags(4 | 2048 | 8192)
         assert run(photo) == [True] * 4                             # forced: the fix-up loop settles the pixels of the class
         eng.set_debug_flags(0)
     finally:
@@ -621,7 +622,7 @@ def test_random_small_images_against_oracle(capi, eng, seed):
         mm_r, mm_c = int(rng.integers(0, max(1, H))), int(rng.integers(0, max(1, W // 2 + 1)))
         # colour: default choice of the class plane, or forced; uint16: default, or one-pass histogram with the plane forced
         # (its classes centred on whatever threshold the shared handle met last), or the two-pass histogram
-        eng.set_debug_flags(int(rng.choice([0, 4, 0, 1024, 1024 | 1, 1024 | 4096])) if kind == 2 else (int(rng.choice([0, 16 | 4, 8])) if kind == 1 else 0))
+        eng.set_debug_flags(int(rng.choice([0, 4, 0, 1024, 1024 | 1, 1024 | 4096, 8192, 16384, 32768, 32768 | 1])) if kind == 2 else (int(rng.choice([0, 16 | 4, 8])) if kind == 1 else 0))
         try:
             check_detect(capi, eng, arr, mm_r, mm_c, L)
         finally:
@@ -850,5 +851,89 @@ def test_a_handle_finds_grey_batches_by_itself(capi, golden_dir):
         speck[:, 100, 37, 1] ^= 0x10
         seen = [run(speck) for _ in range(7)]
         assert all(p == [False] * 3 for p in seen)
+    finally:
+        e.close()
+
+
+def test_predicted_threshold_mode_matches_the_oracle(capi):
+    """A handle that has completed a colour call expects the next call's integer mask thresholds inside the range the last
+    call's had: the histogram pass then writes one bit per pixel (at or above that window) instead of the 4-bit class, lists
+    the pixel groups inside the window, and the mask comes from the bits plus an exact compare of the listed pixels
+    (k_mask_fix).  Checked here: the mode follows the calls made on the handle; every intermediate equals the oracle when the
+    prediction holds, when it fails (another scene: compare on the image), with a window without margin (thresholds ON its
+    ends), with every pixel inside the window (forced: each one goes through the list), and when that list overflows."""
+    from image_analysis_amd.synth import synth_rgb
+    H, W = 384, 512
+    scene = np.stack([synth_rgb(H, W, 5, 70 + k) for k in range(4)])
+    dim = np.ascontiguousarray((scene.astype(np.float64) * 0.45).astype(np.uint8))               # thresholds far below the first scene's
+    soft = scene.copy()                                                                          # blurred strip edges: pixels inside the window
+    for k in range(4):
+        a = soft[k].astype(np.float64)
+        soft[k] = ((a + np.roll(a, 1, axis=1) + np.roll(a, 2, axis=1) + np.roll(a, 3, axis=1)) / 4).astype(np.uint8)
+    mm_r, mm_c = gui_params(scene[0])
+    e = capi.Engine(device=0, max_h=H, max_w=W, max_batch=4)
+    try:
+        def run(batch, L=10):
+            res = e.detect(batch, mm_r, mm_c, L)
+            for i in range(len(batch)):
+                check_detect(capi, e, batch[i], mm_r, mm_c, L, batch_index=i, res=res)
+            return [e.debug_pred_path(i) for i in range(len(batch))]
+        assert run(scene) == [False] * 4                 # nothing to predict from
+        assert run(scene) == [True] * 4
+        e.close()
+        e = capi.Engine(device=0, max_h=H, max_w=W, max_batch=4)
+        assert run(soft) == [False] * 4
+        assert run(soft) == [True] * 4                   # blurred edges: pixels inside the window, decided through the list
+        assert run(scene) == [False] * 4                 # (sharp edges, other extremes: other thresholds)
+        e.close()
+        e = capi.Engine(device=0, max_h=H, max_w=W, max_batch=4)
+        run(scene)
+        assert run(scene[:1]) == [True]
+        assert run(dim) == [False] * 4                   # window of the bright scene: every image falls back to the compare on the image
+        for _ in range(8):
+            assert run(dim) == [False] * 4               # ... and the handle stays out of the mode for eight calls
+        assert run(dim) == [True] * 4
+        mixed = np.stack([dim[0], scene[0], dim[1], dim[2]])
+        assert run(mixed) == [True, False, True, True]   # per image
+        e.close()
+        e = capi.Engine(device=0, max_h=H, max_w=W, max_batch=4)
+        e.set_debug_flags(16384)                         # no margin: window = [smallest, largest] threshold of the call before
+        run(scene)
+        assert run(scene) == [True] * 4                  # two of the thresholds are the window's ends
+        e.set_debug_flags(32768)                         # every pixel inside the window
+        assert run(soft) == [True] * 4
+        assert run(soft, L=100) == [False] * 4           # the list lives in a buffer sized by line_length: it overflows, compare on the image
+        e.set_debug_flags(32768 | 1)                     # float64 compare path: no integer threshold, no bits
+        assert run(scene) == [False] * 4
+        e.set_debug_flags(8192)
+        assert run(scene) == [False] * 4
+        e.set_debug_flags(0)
+    finally:
+        e.close()
+
+
+def test_predicted_threshold_mode_in_analyze_batch_and_across_shapes(capi):
+    """lfa_analyze_batch on one handle, call after call, with shapes and scenes changing in between: strips, profiles and peaks
+    equal the oracle whichever way each call's masks were decided."""
+    from image_analysis_amd.synth import synth_rgb
+    e = capi.Engine(device=0, max_h=384, max_w=512, max_batch=3)
+    try:
+        took = []
+        for step, (H, W, seed, scale) in enumerate([(384, 512, 1, 1.0), (384, 512, 1, 1.0), (192, 256, 3, 1.0), (192, 256, 4, 0.6),
+                                                   (192, 256, 4, 0.6), (384, 496, 6, 1.0), (384, 496, 7, 1.0)]):
+            batch = np.stack([np.ascontiguousarray((synth_rgb(H, W, 4, 100 * seed + k) * scale).astype(np.uint8)) for k in range(3)])
+            mm_r, mm_c = gui_params(batch[0])
+            res, info = e.analyze(batch, mm_r, mm_c)
+            took.append([e.debug_pred_path(i) for i in range(3)])
+            for i, (strips, profiles, peaks) in enumerate(res):
+                d = O.detect_debug(batch[i], mm_r, mm_c)
+                assert capi.host_threshold(info[i], True) == d["threshold"] and info[i]["n_labels"] == d["n_labels"]
+                assert [[int(s["minr"]), int(s["maxr"]), int(s["minc"]), int(s["maxc"])] for s in strips] == d["strips"], (step, i)
+                for k, (a, b, c, w) in enumerate(d["strips"]):
+                    wp, wk = O.image_analysis(batch[i][a:b, c:w], False)
+                    assert np.array_equal(profiles[k], wp)
+                    assert [(int(peaks[k]["start"][q]), int(peaks[k]["end"][q]), float(peaks[k]["area"][q]))
+                            for q in range(int(peaks[k]["n_peaks"]))] == [(s0, e0, float(a0)) for s0, e0, a0 in wk]
+        assert all(took[1]) and not any(took[0])
     finally:
         e.close()

@@ -14,7 +14,7 @@ synth = importlib.import_module("image_analysis_amd.synth")
 H, W, B = 1536, 2048, 256
 dev = torch.device("cuda", 0)
 pool = torch.from_numpy(np.stack([synth.synth_rgb(H, W, 8, 1234 + i) for i in range(16)]).reshape(16, -1)).to(dev)
-batch = pool[torch.arange(B, device=dev) % 16].contiguous()
+batch = pool[torch.arange(B, device=dev) % int(os.environ.get('LFA_KT_POOL', '16'))].contiguous()
 e = capi.Engine(device=0, max_h=H, max_w=W, max_c=3, max_batch=B)
 if len(sys.argv) > 1:
     e.set_debug_flags(int(sys.argv[1]))
@@ -41,4 +41,4 @@ for _ in range(10):
     call()
 torch.cuda.synchronize()
 t = e.timing_read()
-print(os.environ.get("LFA_LIB_PATH", "default"), sys.argv[1:], " ".join(f"{k}={v[0] / v[1]:.4f}" for k, v in sorted(t.items(), key=lambda kv: -kv[1][0])[:5]), flush=True)
+print(os.environ.get("LFA_LIB_PATH", "default"), sys.argv[1:], "pred" if e.debug_pred_path(0) else "",  " ".join(f"{k}={v[0] / v[1]:.4f}" for k, v in sorted(t.items(), key=lambda kv: -kv[1][0])[:5]), flush=True)
