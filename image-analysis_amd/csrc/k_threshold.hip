@@ -332,25 +332,86 @@ __global__ __launch_bounds__(256) void k_grey_hist(Job j) {
 // the lane's running extremes; the float64 gray is evaluated only for a pixel that sets or ties one of them with a byte
 // triple not seen there before (equal G from different triples can differ in the last bits of gray: fmin / fmax decide).
 // A lane updates its extremes a handful of times over its whole share of the image, so the pass costs the integer work.
+//
+// MinMaxLane: a lane's record of the extreme it has seen (G, byte triple, float gray) and the wave-wide bounds Wlo / Whi (the
+// best G any lane of the wave holds), which screen the pixels: one that does not reach them cannot be an extreme of the image.
+template <int V>
+struct MinMaxLane {
+    double lo, hi;
+    uint32_t Glo, Ghi, tlo, thi, Wlo, Whi, notgrey;
+    __device__ __forceinline__ void init() {
+        lo = __longlong_as_double(0x7ff0000000000000LL); hi = 0.0;
+        Glo = 0x7fffffffu; Ghi = 0u; tlo = 0xffffffffu; thi = 0xffffffffu; Wlo = 0x7fffffffu; Whi = 0u; notgrey = 0u;
+    }
+    // One round: w = the lane's 16 pixels (48 bytes), t48 = the same twelve dwords in LDS (the wave's turn buffer).  ALL 64
+    // lanes of the wave must be here (wave reductions).
+    __device__ __forceinline__ void round(const uint32_t (&w)[12], const uint32_t* t48, bool look_grey) {
+        auto pixel = [&](int k) -> uint32_t {             // bytes 3k .. 3k+2 of the group at the low end of a dword (k constant after unrolling)
+            const int i = (3 * k) >> 2, sft = (3 * k) & 3;
+            return sft == 0 ? w[i] : (sft == 1 ? (w[i] >> 8) : __builtin_amdgcn_alignbyte(w[i + 1 < 12 ? i + 1 : i], w[i], sft));
+        };
+        if (look_grey) notgrey |= not_grey16(w);
+        bool reach = false;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t Gk = gray_G_from_dword(pixel(k));  // (the dot products give the fourth byte weight 0)
+            reach |= Gk <= Wlo || Gk >= Whi;
+        }
+        if (!__any(reach)) return;                        // the usual case: nothing in the wave's 1024 pixels reaches a bound
+        // Some pixel reaches a bound: it matters only with a byte triple other than the one this lane already holds there
+        // (the same triple again -- a black or saturated area -- changes nothing).  Rare, so this part is written for few
+        // registers, not for speed (the screen above runs all the time and its occupancy is what counts): the pixels are
+        // walked one by one out of the lane's 48 bytes in LDS.
+        bool changed = false;
+        auto one = [&](uint32_t t) {
+            const uint32_t Gk = gray_G_from_dword(t);
+            const bool nlo = Gk <= Wlo && Gk <= Glo && t != tlo, nhi = Gk >= Whi && Gk >= Ghi && t != thi;
+            if (nlo || nhi) {
+                const double gr = gray_u8<V>(t & 0xffu, (t >> 8) & 0xffu, t >> 16);
+                if (nlo) { lo = (Gk < Glo) ? gr : fmin(lo, gr); Glo = Gk; tlo = t; }
+                if (nhi) { hi = (Gk > Ghi) ? gr : fmax(hi, gr); Ghi = Gk; thi = t; }
+                changed = true;
+            }
+        };
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) {
+            const int b0 = 3 * k;
+            const uint32_t lo32 = t48[b0 >> 2], hi32 = t48[min((b0 >> 2) + 1, 11)];
+            one((uint32_t)((((uint64_t)hi32 << 32) | lo32) >> (8 * (b0 & 3))) & 0xffffffu);
+        }
+        if (!__any(changed)) return;
+        Wlo = (uint32_t)wave_min_i32((int)Glo);               // (G <= 2 550 000 orders the same signed or unsigned; a lane that has
+        Whi = (uint32_t)wave_max_i32((int)Ghi);               //  seen nothing yet reports INT_MAX / 0)
+    }
+    // The block's extremes into the image's record (bit patterns of non-negative doubles order like the doubles).  Every thread
+    // of the 256-thread block must call it; slo / shi: four doubles of LDS each.
+    __device__ __forceinline__ void commit(double* slo, double* shi, unsigned long long* gmin_bits, unsigned long long* gmax_bits) {
+        lo = wave_min_f64(lo); hi = wave_max_f64(hi);
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { slo[wv] = lo; shi[wv] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; ++k) { lo = fmin(lo, slo[k]); hi = fmax(hi, shi[k]); }
+            atomicMin(gmin_bits, (unsigned long long)__double_as_longlong(lo));
+            atomicMax(gmax_bits, (unsigned long long)__double_as_longlong(hi));
+        }
+    }
+};
+
 template <int V>
 __global__ __launch_bounds__(256) void k_minmax_rgb(Job j) {
     const int img = blockIdx.y;
     const uint8_t* base = j.images + (int64_t)img * j.img_bytes;
     const int64_t npix = (int64_t)j.H * j.W;
-    double lo = __longlong_as_double(0x7ff0000000000000LL), hi = 0.0;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * blockDim.x;
     int64_t done = 0;
     uint32_t* grey_flag = j.edges_i + (int64_t)img * kEdgesI + kEdgesI_Grey;
     if (j.grey_mode && *grey_flag) return;            // k_grey_hist found three equal channels throughout: k_edges_rgb has the extremes
-    uint32_t notgrey = 0;                             // otherwise this pass looks out for such images on the way (for the handle's next call)
+    MinMaxLane<V> m;                                  // (otherwise this pass looks out for such images on the way, for the handle's next call)
+    m.init();
     if (j.aligned16) {
         const int64_t ng = npix >> 4;                 // groups of 16 pixels = 48 bytes
-        // lane-private record of the extreme it has seen (G, byte triple, float gray); wave-wide bounds Wlo / Whi (the best G
-        // any lane of the wave holds) screen the pixels: one that does not reach them cannot be an extreme of the image
-        __shared__ uint32_t stash[12 * 256];
-        uint32_t Glo = 0x7fffffffu, Ghi = 0u, tlo = 0xffffffffu, thi = 0xffffffffu;
-        uint32_t Wlo = 0x7fffffffu, Whi = 0u;
         const int lane = threadIdx.x & 63, wv4 = threadIdx.x >> 6;
         // Memory shape (tools/read_probe.hip): a lane that loads its own 48 bytes as three 16-byte pieces reads at 6.2 TB/s; fully
         // coalesced 16-byte nontemporal loads over a contiguous run per block read at 7.1.  So a wave takes a round of 64 groups
@@ -384,65 +445,20 @@ __global__ __launch_bounds__(256) void k_minmax_rgb(Job j) {
                 const lfa_u32x4 v = turn[wv4][3 * mine48 + k];
                 w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w;
             }
-            auto pixel = [&](int k) -> uint32_t {             // bytes 3k .. 3k+2 of the group at the low end of a dword (k constant after unrolling)
-                const int i = (3 * k) >> 2, sft = (3 * k) & 3;
-                return sft == 0 ? w[i] : (sft == 1 ? (w[i] >> 8) : __builtin_amdgcn_alignbyte(w[i + 1 < 12 ? i + 1 : i], w[i], sft));
-            };
-            // (a hint for the handle's next call, so one round in four is looked at: +1 % on this pass instead of +4 %; the
-            //  equal-channel pass itself checks every pixel)
-            if (!j.grey_mode && ((r >> 2) & 3) == 0) notgrey |= not_grey16(w);
-            bool reach = false;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t Gk = gray_G_from_dword(pixel(k));  // (the dot products give the fourth byte weight 0)
-                reach |= Gk <= Wlo || Gk >= Whi;
-            }
-            if (!__any(reach)) continue;                      // the usual case: nothing in the wave's 1024 pixels reaches a bound
-            // Some pixel reaches a bound: it matters only with a byte triple other than the one this lane already holds there
-            // (the same triple again -- a black or saturated area -- changes nothing).  Rare, so this part is written for few
-            // registers, not for speed (the loop above runs all the time and its occupancy is what counts): the lane's 48
-            // bytes go to LDS and the pixels are walked one by one.
-            uint32_t* mine = stash + threadIdx.x;                 // dword d of this lane at stash[d * 256 + threadIdx.x]
-#pragma unroll
-            for (int d = 0; d < 12; ++d) mine[d * 256] = w[d];
-            bool changed = false;
-#pragma unroll 1
-            for (int k = 0; k < 16; ++k) {
-                const int b0 = 3 * k;
-                const uint32_t lo32 = mine[(b0 >> 2) * 256], hi32 = mine[min((b0 >> 2) + 1, 11) * 256];
-                const uint32_t t = (uint32_t)((((uint64_t)hi32 << 32) | lo32) >> (8 * (b0 & 3))) & 0xffffffu;
-                const uint32_t Gk = gray_G_from_dword(t);
-                const bool nlo = Gk <= Wlo && Gk <= Glo && t != tlo, nhi = Gk >= Whi && Gk >= Ghi && t != thi;
-                if (nlo || nhi) {
-                    const double gr = gray_u8<V>(t & 0xffu, (t >> 8) & 0xffu, t >> 16);
-                    if (nlo) { lo = (Gk < Glo) ? gr : fmin(lo, gr); Glo = Gk; tlo = t; }
-                    if (nhi) { hi = (Gk > Ghi) ? gr : fmax(hi, gr); Ghi = Gk; thi = t; }
-                    changed = true;
-                }
-            }
-            if (!__any(changed)) continue;
-            Wlo = (uint32_t)wave_min_i32((int)Glo);               // (G <= 2 550 000 orders the same signed or unsigned; a lane that has
-            Whi = (uint32_t)wave_max_i32((int)Ghi);               //  seen nothing yet reports INT_MAX / 0)
+            // (the grey look is a hint for the handle's next call, so one round in four is looked at: +1 % on this pass instead of
+            //  +4 %; the equal-channel pass itself checks every pixel)
+            m.round(w, (const uint32_t*)&turn[wv4][3 * mine48], !j.grey_mode && ((r >> 2) & 3) == 0);
         }
         done = ng << 4;
-        if (notgrey) *grey_flag = 0u;
+        if (m.notgrey) *grey_flag = 0u;
     }
     // uint16 colour and float64 images: this scalar loop only (Job::aligned16 is 0 for them)
     for (int64_t p = done + tid; p < npix; p += nth) {
         const double gr = gray_at<V>(base, p, j.dtype, j.C);
-        lo = fmin(lo, gr); hi = fmax(hi, gr);
+        m.lo = fmin(m.lo, gr); m.hi = fmax(m.hi, gr);
     }
-    lo = wave_min_f64(lo); hi = wave_max_f64(hi);
     __shared__ double slo[4], shi[4];
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { slo[wv] = lo; shi[wv] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 4; ++k) { lo = fmin(lo, slo[k]); hi = fmax(hi, shi[k]); }
-        // non-negative doubles order like their bit patterns
-        atomicMin((unsigned long long*)&j.info[img].gmin, (unsigned long long)__double_as_longlong(lo));
-        atomicMax((unsigned long long*)&j.info[img].gmax, (unsigned long long)__double_as_longlong(hi));
-    }
+    m.commit(slo, shi, (unsigned long long*)&j.info[img].gmin, (unsigned long long*)&j.info[img].gmax);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
