@@ -448,7 +448,7 @@ hipError_t launch_debug(const Job& j, int image, int what, void* out, int64_t ou
             break;
         case LFA_DBG_PLANE:
             if (out_bytes < 4) return hipErrorInvalidValue;
-            if ((j.C == 3 || j.u16_plane) && j.bins) e = hipMemcpyAsync(out, j.edges_i + (int64_t)image * kEdgesI + kEdgesI_Bins, 4, hipMemcpyDeviceToDevice, s);
+            if ((j.C == 3 || j.u16_plane || j.pred_mode) && j.bins) e = hipMemcpyAsync(out, j.edges_i + (int64_t)image * kEdgesI + kEdgesI_Bins, 4, hipMemcpyDeviceToDevice, s);
             else e = hipMemsetAsync(out, 0, 4, s);
             if (e != hipSuccess) return e;
             break;

@@ -37,10 +37,25 @@ __global__ __launch_bounds__(256) void k_mask_fix(Job j) {
     const uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
     if (eg[kEdgesI_Bins] != 2u) return;
     const uint32_t n = min(eg[kEdgesI_PredCnt], (uint32_t)j.pred_cap);
-    const uint32_t G_thr = eg[kEdgesI_MaskThr], t_lo = j.pred_lo, t_hi = j.pred_hi;
+    const uint32_t t_lo = j.pred_lo, t_hi = j.pred_hi;
     const uint32_t* list = j.pred_list + (int64_t)img * j.pred_stride;
     const uint8_t* base = j.images + (int64_t)img * j.img_bytes;
     uint64_t* out = j.maskT + (int64_t)img * j.HB * j.W;
+    if (j.dtype == LFA_U16) {                                             // uint16 frames: pixel >= T = x_thr + 1
+        const uint32_t T = (uint32_t)j.info[img].x_thr + 1u;
+        for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+            const int64_t p0 = (int64_t)list[e] * 16;
+            const int r = (int)(p0 / j.W), c0 = (int)(p0 % j.W);
+            const uint16_t* px = (const uint16_t*)base + p0;
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t x = px[k];
+                if (x >= t_lo && x < t_hi && x >= T)
+                    atomicOr((unsigned long long*)&out[(int64_t)(r >> 6) * j.W + c0 + k], 1ull << (r & 63));
+            }
+        }
+        return;
+    }
+    const uint32_t G_thr = eg[kEdgesI_MaskThr];
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
         const int64_t p0 = (int64_t)list[e] * 16;                         // W % 16 == 0: a group never crosses a row
         const int r = (int)(p0 / j.W), c0 = (int)(p0 % j.W);
@@ -80,7 +95,7 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
             G_thr = eg[kEdgesI_MaskThr];
             integer_path = eg[kEdgesI_MaskCrit] == 0;
         }
-        if (PRED && VEC && MODE == 2 && j.bins && eg[kEdgesI_Bins] == 2u) {
+        if (PRED && VEC && j.bins && eg[kEdgesI_Bins] == 2u) {
             // Predicted-threshold bit plane (Job::pred_mode): bit = G >= pred_hi, row-major, 16 pixels = one 16-bit word.  The
             // image's threshold lies inside the window, so a set bit is a set pixel and a clear bit a clear pixel except for
             // the listed pixels inside the window, which k_mask_fix ORs in afterwards.  What remains here is turning 64 rows
@@ -354,7 +369,7 @@ static void launch_mode(const Job& j, hipStream_t s) {
     const bool vec = j.aligned16 && (j.W % 16 == 0);
     if (vec) {
         const int64_t items = (int64_t)j.HB * (j.W >> 4);
-        if (MODE == 2 && j.pred_mode) {
+        if (MODE != 0 && j.pred_mode) {
             LFA_LAUNCH("k_mask", (k_mask<MODE, V, true, true>), dim3((unsigned)((items + 255) / 256), j.n), dim3(256), 0, s, j);
             LFA_LAUNCH("k_mask_fix", k_mask_fix, dim3(4, j.n), dim3(256), 0, s, j);
         } else {

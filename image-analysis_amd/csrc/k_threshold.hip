@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void k_init_info(Job j) {
         j.info[img] = z;
         j.edges_i[(int64_t)img * kEdgesI + kEdgesI_Grey] = (j.C == 3 && j.dtype == LFA_U8 && j.aligned16) ? 1u : 0u;
         j.edges_i[(int64_t)img * kEdgesI + kEdgesI_PredCnt] = 0u;
+        if (j.thr_list) j.thr_list[img] = 0u;
     }
     if (j.hist_stride == 256) {
         uint32_t* gh = j.hist + (int64_t)img * 256;
@@ -497,6 +498,10 @@ __global__ __launch_bounds__(256) void k_hist_u8(Job j) {
 }
 
 
+// KIND 0: histogram only; 1: also the 4-bit class plane (Job::u16_plane); 2: also the predicted-threshold bit plane and the list of
+// undecided groups (Job::pred_mode) -- three kernels, so that each keeps only its own pointers and bounds in scalar registers (the
+// one kernel for all three needed 102 of them: seven waves per SIMD, i.e. ONE 1024-thread block per CU instead of two)
+template <int KIND>
 __global__ __launch_bounds__(1024) void k_hist_u16(Job j) {
     __shared__ uint32_t sh[kLdsBinsU16];
     const int img = blockIdx.y;
@@ -535,15 +540,49 @@ __global__ __launch_bounds__(1024) void k_hist_u16(Job j) {
         const uint4* v = (const uint4*)base;
         // class plane (Job::u16_plane, one-pass form only): 4 bits per pixel, pixel p in nibble p & 7 of dword p >> 3 --
         // the layout k_mask reads for colour images; 8 bytes per lane and step
-        uint2* plane = j.u16_plane ? (uint2*)(j.bins + (((int64_t)img * npix) >> 1)) : nullptr;
+        uint2* plane = KIND == 1 ? (uint2*)(j.bins + (((int64_t)img * npix) >> 1)) : nullptr;
         const uint32_t pa = (uint32_t)j.u16_pa;
         const int ps = j.u16_ps;
+        // Predicted-threshold mode (Job::pred_mode, as for colour images): with T = x_thr + 1 the mask is `pixel >= T`, and the
+        // handle's last call gives a window [pred_lo, pred_hi] in which this call's T are expected.  One bit per pixel, pixel >=
+        // pred_hi, 16 pixels = one 16-bit word; a group holding a pixel with pred_lo <= pixel < pred_hi goes on the image's list
+        // (k_mask_fix decides those pixels once T is known).  1/8 byte per pixel written instead of 1/2.
+        uint16_t* pbits = KIND == 2 ? (uint16_t*)(j.bins + (int64_t)img * (npix >> 3)) : nullptr;
+        uint32_t* pcnt = j.edges_i + (int64_t)img * kEdgesI + kEdgesI_PredCnt;
+        uint32_t* plist = KIND == 2 ? j.pred_list + (int64_t)img * j.pred_stride : nullptr;
+        const uint32_t t_lo = j.pred_lo, t_hi = j.pred_hi, pcap = (uint32_t)j.pred_cap;
+        // The next step's 32 bytes are requested before this step's 16 pixels are counted, and a plane's store stays in flight
+        // across the loop boundary (loads, store and waits issued by hand, lfa_device.h): left to the compiler the loop asks for
+        // its bytes at the top of every step and waits for them with nothing else to do.
+        lfa_u32x4 n0, n1;
+        if (tid < ng) { vm_request32(v + 2 * tid, n0, n1); vm_wait32<0>(n0, n1); }
+        constexpr bool stores = KIND != 0;                            // one store per lane and step
         for (int64_t g = tid; g < ng; g += nth) {
-            const uint4 q0 = v[2 * g], q1 = v[2 * g + 1];
-            const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const uint32_t w[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+            const int64_t gn = g + nth < ng ? g + nth : g;                // (the last step asks for its own bytes again; the copy is not used)
+            vm_request32(v + 2 * gn, n0, n1);
 #pragma unroll
             for (int k = 0; k < 8; ++k) { count((int)(w[k] & 0xffffu) - xmin); count((int)(w[k] >> 16) - xmin); }
-            if (plane) {
+            if (KIND == 2) {
+                uint32_t set = 0, und = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t x = (w[k >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                    set |= (x >= t_hi ? 1u : 0u) << k;
+                    und |= (x >= t_lo && x < t_hi) ? 1u : 0u;
+                }
+                const unsigned long long um = __ballot(und != 0u);    // (over the lanes still in the loop)
+                if (um) {                                             // rare: the valley of the histogram
+                    const int lane = threadIdx.x & 63, leader = __ffsll(um) - 1;
+                    uint32_t slot0 = 0;
+                    if (lane == leader) slot0 = atomicAdd(pcnt, (uint32_t)__popcll(um));
+                    slot0 = (uint32_t)__shfl((int)slot0, leader);
+                    const uint32_t slot = slot0 + (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
+                    if (und != 0u && slot < pcap) plist[slot] = (uint32_t)g;
+                }
+                vm_store2(pbits + g, set);
+            }
+            if (KIND == 1) {
                 uint32_t cls[2] = {0u, 0u};
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
@@ -553,6 +592,9 @@ __global__ __launch_bounds__(1024) void k_hist_u16(Job j) {
                 }
                 vm_store8(plane + g, cls[0], cls[1]);
             }
+            // the requested bytes are in; issued after them: this step's store (more when the list took something: the wait then
+            // is merely earlier), which may still be on its way
+            if (stores) vm_wait32<1>(n0, n1); else vm_wait32<0>(n0, n1);
         }
         done = ng << 4;
     }
@@ -788,11 +830,12 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
     LfaImageInfo* inf = &j.info[img];
     const uint32_t* gh = j.hist + (int64_t)img * j.hist_stride;
     const int t = threadIdx.x;
-    __shared__ int s_lo, s_hi;
+    __shared__ int s_lo, s_hi, s_xthr;                          // s_xthr: x_thr of a uint16 frame on the one-pass histogram (else < 0), for the block-wide tail
     __shared__ unsigned long long s_w[4], s_s[4];
     __shared__ double s_bv[4];
     __shared__ int s_bi[4];
     int xmin, xmax;
+    if (t == 0) s_xthr = -1;
     const bool abs_hist = j.dtype == LFA_U8 || j.hist_abs;      // bins are pixel values
     if (j.dtype == LFA_U8) {
         // histogram covers 0..255; find occupied range
@@ -926,6 +969,51 @@ __global__ __launch_bounds__(256) void k_otsu_int(Job j) {
                 if (j.plane_stats) { if (could) atomicAdd(&j.plane_stats[6], 1u); atomicAdd(&j.plane_stats[7], 1u); }
                 eg[kEdgesI_Class] = (uint32_t)q | (settled ? 0x100u : 0u);
                 eg[kEdgesI_Bins] = (j.u16_plane && (could || (j.debug_flags & 4))) ? 1u : 0u;
+            }
+            if (j.dtype == LFA_U16 && j.hist_abs) {
+                // Predicted-threshold mode.  Every one-pass call reports the range of its T = x_thr + 1 (the next call's window,
+                // lfa_api.hip); below, whether the window the handle has in mind would have held this frame.
+                const uint32_t T = (uint32_t)x_thr + 1u;
+                s_xthr = x_thr;
+                if (j.pred_mode) {
+                    // the bit plane decides this frame iff T lies inside the window it was written for and the list holds every undecided group
+                    const bool held = T >= j.pred_lo && T <= j.pred_hi && eg[kEdgesI_PredCnt] <= (uint32_t)j.pred_cap;
+                    eg[kEdgesI_Bins] = held ? 2u : 0u;
+                    if (j.plane_stats) { atomicAdd(&j.plane_stats[14], 1u); if (held) atomicAdd(&j.plane_stats[15], 1u); }
+                }
+            }
+        }
+    }
+    // Would the window the handle has in mind (Job::pred_probe_lo / _hi, from its last completed call) have held this frame: T inside
+    // it and at most 1/2048 of the pixels inside it -- a window reaching into the background noise fills the list of undecided
+    // groups.  The handle takes the predicted-threshold mode only while at least half of its last call's frames say yes, so a
+    // series whose thresholds lie inside the noise never pays for a failed try.  Counted from the histogram by the whole block.
+    // Only frames with few pixels near their threshold -- at most 1/1024 within 8 values of it -- shape the next window: one whose
+    // threshold fell into the background noise could not use the bits anyway.  The handle gets every such frame's T (lfa_api.hip
+    // looks for the tightest cluster: one frame of another scene in the batch must not stretch the window over everything between).
+    if (j.dtype == LFA_U16 && j.hist_abs && j.plane_stats) {
+        __shared__ unsigned long long s_in, s_near;
+        __syncthreads();                                             // (s_xthr)
+        const int x_thr = s_xthr;
+        if (t == 0) { s_in = 0ull; s_near = 0ull; }
+        __syncthreads();
+        if (x_thr >= 0) {
+            if (t < 16) { const int x = x_thr - 7 + t; if (x >= 0 && x <= 65535) { const uint32_t c = gh[x]; if (c) atomicAdd(&s_near, (unsigned long long)c); } }
+            unsigned long long c = 0;
+            for (uint32_t x = j.pred_probe_lo + (uint32_t)t; x < j.pred_probe_hi && x < 65536u; x += 256u) c += gh[x];
+            if (c) atomicAdd(&s_in, c);
+        }
+        __syncthreads();
+        if (t == 0 && x_thr >= 0) {
+            const uint32_t T = (uint32_t)x_thr + 1u;
+            const unsigned long long npx = (unsigned long long)((int64_t)j.H * j.W);
+            const bool sparse = s_near * 1024ull <= npx;
+            if (sparse) { atomicMax(&j.plane_stats[12], 0x7fffffffu - T); atomicMax(&j.plane_stats[13], T); }
+            if (j.thr_list) j.thr_list[img] = sparse ? T : 0u;
+            if (j.pred_probe_hi > j.pred_probe_lo) {
+                const bool would = T >= j.pred_probe_lo && T <= j.pred_probe_hi && s_in * 2048ull <= npx;
+                if (would) atomicAdd(&j.plane_stats[16], 1u);
+                atomicAdd(&j.plane_stats[17], 1u);
             }
         }
     }
@@ -1121,8 +1209,12 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
             LFA_LAUNCH("k_minmax_u16", k_minmax_u16, grid, dim3(256), 0, s, j);
             LFA_LAUNCH("k_zero_hist_u16", k_zero_hist_u16, dim3(16, j.n), dim3(256), 0, s, j);
         }
-        const dim3 gridh(blocks_per_image(j, 1024 * 64), j.n);
-        LFA_LAUNCH("k_hist_u16", k_hist_u16, gridh, dim3(1024), 0, s, j);
+        static const int u16_threads = [] { const char* e = getenv("LFA_U16_THREADS"); return e ? atoi(e) : 1024; }();
+        static const int u16_ppt = [] { const char* e = getenv("LFA_U16_PPT"); return e ? atoi(e) : 64; }();
+        const dim3 gridh(blocks_per_image(j, u16_threads * u16_ppt), j.n);
+        if (j.pred_mode && j.bins) LFA_LAUNCH("k_hist_u16", k_hist_u16<2>, gridh, dim3(u16_threads), 0, s, j);
+        else if (j.u16_plane && j.bins) LFA_LAUNCH("k_hist_u16", k_hist_u16<1>, gridh, dim3(u16_threads), 0, s, j);
+        else LFA_LAUNCH("k_hist_u16", k_hist_u16<0>, gridh, dim3(u16_threads), 0, s, j);
         if (j.passes_event) (void)hipEventRecord(j.passes_event, s);
         LFA_LAUNCH("k_otsu_int", k_otsu_int, dim3(j.n), dim3(256), 0, s, j);
     }

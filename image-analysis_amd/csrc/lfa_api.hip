@@ -1,6 +1,7 @@
 // lfa_api.hip -- host side of the C ABI declared in include/lfa.h: handle, workspace, argument checks, launch order.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -164,6 +165,14 @@ struct LfaContext {
     bool pred_have = false, pending_pred = false;
     uint32_t pred_lo = 0, pred_hi = 0;
     int pred_backoff = 0;
+    // (uint16 frames on the one-pass histogram take the same mode with the pixel value in place of G: the window is the range of T = x_thr + 1
+    // of the last completed call widened by max(4, that range) either way, and the handle tries only while at least half of that call's frames
+    // had few pixels near their threshold (k_otsu_int).  pred_kind: what the window was measured on -- 2 colour uint8, 1 uint16, 0 none.)
+    int pred_kind = 0, pending_pred_kind = 0;
+    bool pred_sparse = false;
+    Buf thr_list;                          // [max_batch] T of the frames of a uint16 call (Job::thr_list), copied to thr_host behind the counters
+    uint32_t* thr_host = nullptr;          // pinned
+    int pending_n = 0;
     // uint16 images: the histogram pass needs no min/max pass before it when the bins are the pixel values themselves (one
     // pass less over the image); worth it while the values stay below the LDS table of k_hist_u16 (camera data of 12-14
     // bits).  Chosen from the largest value of the last completed uint16 call, which travels with the counters above.
@@ -183,7 +192,7 @@ struct LfaContext {
     bool have_lines = false;
     std::vector<Buf*> all() {
         std::vector<Buf*> v = ws.all();
-        v.push_back(&lut8); v.push_back(&lut16); v.push_back(&plane_stats); v.push_back(&roi_idx);
+        v.push_back(&lut8); v.push_back(&lut16); v.push_back(&plane_stats); v.push_back(&roi_idx); v.push_back(&thr_list);
         for (Buf* b : {&ln_g, &ln_u, &ln_binlut, &ln_maps, &ln_levels, &ln_lhist, &ln_lval, &ln_cls, &ln_clsfn, &ln_cimg, &ln_parent, &ln_bbox, &ln_cand, &ln_info})
             v.push_back(b);
         return v;
@@ -340,10 +349,22 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
     if (pred_shape && (h->debug_flags & 32768)) {
         j.pred_mode = 1; j.pred_lo = 0u; j.pred_hi = 0x400000u;
         j.pred_cap = (int32_t)(groups < room ? groups : room);
-    } else if (pred_shape && h->pred_have && h->pred_backoff == 0) {
+    } else if (pred_shape && h->pred_have && h->pred_kind == 2 && h->pred_backoff == 0) {
         j.pred_mode = 1; j.pred_lo = h->pred_lo & ~1023u; j.pred_hi = (h->pred_hi + 1023u) & ~1023u;      // whole buckets of k_hist_rgb's table
         j.pred_cap = (int32_t)(groups / 16 < room ? groups / 16 : room);
     }
+    const bool pred_shape_u16 = C == 1 && dtype == LFA_U16 && j.hist_abs && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & (2 | 8192)) &&
+                                w.bins.bytes >= (size_t)n * (((size_t)H * W + 1) / 2);
+    if (pred_shape_u16 && (h->debug_flags & 32768)) {
+        j.pred_mode = 1; j.pred_lo = 0u; j.pred_hi = 65536u;
+        j.pred_cap = (int32_t)(groups < room ? groups : room);
+    } else if (pred_shape_u16 && h->pred_have && h->pred_kind == 1 && h->pred_backoff == 0 && h->pred_sparse) {
+        j.pred_mode = 1; j.pred_lo = h->pred_lo; j.pred_hi = h->pred_hi;
+        j.pred_cap = (int32_t)(groups / 16 < room ? groups / 16 : room);
+    }
+    if (j.pred_mode && dtype == LFA_U16) j.u16_plane = 0;          // (one plane per call: the bits take the class plane's place)
+    if (C == 1 && dtype == LFA_U16 && j.hist_abs && h->pred_have && h->pred_kind == 1) { j.pred_probe_lo = h->pred_lo; j.pred_probe_hi = h->pred_hi; }
+    j.thr_list = (C == 1 && dtype == LFA_U16 && j.hist_abs) ? (uint32_t*)h->thr_list.p : nullptr;
     j.pred_list = (uint32_t*)w.bbox.p;
     j.pred_stride = room;
     j.bins = (j.u16_plane || rgb_plane || j.pred_mode) ? (uint8_t*)w.bins.p : nullptr;
@@ -433,11 +454,31 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         {
             const uint32_t tmin = 0x7fffffffu - h->plane_host[12], tmax = h->plane_host[13];
             h->pred_have = h->plane_host[12] != 0u && tmin <= tmax;
-            if (h->pred_have) {
+            h->pred_kind = h->pred_have ? h->pending_pred_kind : 0;
+            if (h->pred_have && h->pred_kind == 1) {
+                // uint16: the tightest cluster of the call's T values -- the largest set within 32 values of each other --, provided it
+                // holds at least half of the frames; widened by max(4, its own range) either way
+                std::vector<uint32_t> T;
+                for (int k = 0; k < h->pending_n; ++k) if (h->thr_host[k]) T.push_back(h->thr_host[k]);
+                std::sort(T.begin(), T.end());
+                size_t best_i = 0, best_c = 0;
+                for (size_t i = 0, e = 0; i < T.size(); ++i) {
+                    while (e < T.size() && T[e] - T[i] <= 32u) ++e;
+                    if (e - i > best_c) { best_c = e - i; best_i = i; }
+                }
+                h->pred_have = best_c > 0 && 2 * best_c >= (size_t)h->pending_n;
+                if (h->pred_have) {
+                    const uint32_t c_lo = T[best_i], c_hi = T[best_i + best_c - 1];
+                    const uint32_t margin = (h->debug_flags & 16384) ? 0u : (c_hi - c_lo > 4u ? c_hi - c_lo : 4u);
+                    h->pred_lo = c_lo > margin ? c_lo - margin : 0u;
+                    h->pred_hi = c_hi + margin;
+                } else h->pred_kind = 0;
+            } else if (h->pred_have) {
                 const uint32_t margin = (h->debug_flags & 16384) ? 0u : 16384u;
                 h->pred_lo = tmin > margin ? tmin - margin : 0u;
                 h->pred_hi = tmax + margin;
             }
+            h->pred_sparse = h->plane_host[17] != 0u && 2u * h->plane_host[16] >= h->plane_host[17];
             if (h->pending_pred && h->plane_host[14] && 2u * h->plane_host[15] < h->plane_host[14]) h->pred_backoff = 8;
             else if (h->pred_backoff > 0) --h->pred_backoff;
         }
@@ -463,7 +504,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         // no events either: nothing is recorded for, or awaited from, other handles (lfa_stream_wait_passes /
         // lfa_chain_passes do not see static calls), so the call is kernels and memsets on `s` only and can be captured
         j.passes_event = nullptr; j.wait_event = nullptr;
-        j.pred_mode = 0; j.pred_list = nullptr;
+        j.pred_mode = 0; j.pred_list = nullptr; j.thr_list = nullptr; j.pred_probe_lo = j.pred_probe_hi = 0u;
         j.plane_stats = nullptr; j.bins = nullptr; j.u16_plane = 0; j.hist_abs = 0; j.win_hint = 0; j.grey_mode = 0; j.grey_plane = nullptr;
         j.u16_lds_bins = lfa::kLdsBinsU16; j.u16_pred = 0; j.u16_pa = 0; j.u16_ps = 0;
         if (ws_rois) *ws_rois = (LfaRoi*)w.rois.p;
@@ -489,6 +530,9 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         h->pending_had_pred = h->u16_have_pred;
         h->pending_grey = j.grey_mode != 0;
         h->pending_pred = j.pred_mode != 0;
+        h->pending_pred_kind = (C == 3 && dtype == LFA_U8) ? 2 : ((C == 1 && dtype == LFA_U16) ? 1 : 0);
+        if (j.thr_list) LFA_HIP(hipMemcpyAsync(h->thr_host, h->thr_list.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        h->pending_n = j.thr_list ? n : 0;
         LFA_HIP(hipEventRecord(h->plane_event, s));
         h->plane_pending = true;
     }
@@ -551,6 +595,11 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         return fail(LFA_ERR_NOMEM, "hipHostMalloc failed");
     }
     for (int k = 0; k < lfa::kStatsWords; ++k) h->plane_host[k] = 0u;
+    if ((rc = ensure(h->thr_list, (size_t)max_batch * 4))) { lfa_destroy(h); return rc; }
+    if (hipHostMalloc((void**)&h->thr_host, (size_t)max_batch * 4, hipHostMallocDefault) != hipSuccess) {
+        h->thr_host = nullptr; lfa_destroy(h);
+        return fail(LFA_ERR_NOMEM, "hipHostMalloc failed");
+    }
     if (hipEventCreateWithFlags(&h->plane_event, hipEventDisableTiming) != hipSuccess) {
         h->plane_event = nullptr; lfa_destroy(h);
         return fail(LFA_ERR_HIP, "hipEventCreate failed");
@@ -572,6 +621,7 @@ int lfa_destroy(LfaHandle h) {
     if (h->done_event) (void)hipEventDestroy(h->done_event);
     if (h->plane_event) (void)hipEventDestroy(h->plane_event);
     if (h->plane_host) (void)hipHostFree(h->plane_host);
+    if (h->thr_host) (void)hipHostFree(h->thr_host);
     delete h->timer;
     delete h;
     return LFA_OK;

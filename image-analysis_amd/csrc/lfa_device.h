@@ -107,6 +107,17 @@ __device__ __forceinline__ void vm_request48(const uint8_t* p, Raw48& r) {      
                  "global_load_dwordx4 %2, %3, off offset:32"
                  : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c) : "v"(p));
 }
+// 32 bytes from a 16-byte aligned address (2 operations), and the wait that releases them
+__device__ __forceinline__ void vm_request32(const void* p, lfa_u32x4& a, lfa_u32x4& b) {
+    asm volatile("global_load_dwordx4 %0, %2, off\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16"
+                 : "=&v"(a), "=&v"(b) : "v"(p));
+}
+template <int LEFT>
+__device__ __forceinline__ void vm_wait32(lfa_u32x4& a, lfa_u32x4& b) {
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(LEFT) : "memory");
+    asm volatile("" : "+v"(a), "+v"(b));
+}
 // three 16-byte pieces at three addresses (a wave's fully coalesced loads of a 3 KiB round), read-once hint
 __device__ __forceinline__ void vm_request3nt(const uint8_t* p0, const uint8_t* p1, const uint8_t* p2, Raw48& r) {   // 3 operations
     asm volatile("global_load_dwordx4 %0, %3, off nt\n\t"
@@ -119,7 +130,13 @@ __device__ __forceinline__ void vm_store8(void* p, uint32_t lo, uint32_t hi) {  
     asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void vm_store2(void* p, uint32_t v) {                              // 1 operation (low 16 bits of v)
+    // (no `nt`: the bit plane is read back by k_mask within the call; with the read-once hint k_hist_rgb took 0.479 ms per 256 images
+    //  instead of 0.462 -- its time without any store -- and k_mask 0.056 instead of 0.046; -DLFA_STORE2_NT restores the hint)
+#ifdef LFA_STORE2_NT
     asm volatile("global_store_short %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+#else
+    asm volatile("global_store_short %0, %1, off" : : "v"(p), "v"(v) : "memory");
+#endif
 }
 __device__ __forceinline__ void vm_store16(void* p, const lfa_u32x4& v) {                     // 1 operation
     asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");

@@ -25,7 +25,7 @@ constexpr int kEdgesI_Grey = 262;        // colour uint8 images on the vector pa
 constexpr int kEdgesI_PredCnt = 263;     // predicted-threshold mode: entries k_hist_rgb asked for in the image's list of undecided pixel groups
                                          // (k_init_info clears it; above Job::pred_cap = the list overflowed)
 constexpr int kHostPowDoubles = 2 + 257 + 256;   // sizeof(LfaHostPow) / 8
-constexpr int kStatsWords = 16;          // Job::plane_stats
+constexpr int kStatsWords = 18;          // Job::plane_stats
 constexpr int kAreaMin = 100;            // detection.py:81
 constexpr int kMaxCand = 1 << 20;
 
@@ -54,8 +54,10 @@ struct Job {
     uint32_t* edges_i;       // [n][264]  the same as integer thresholds on G = 2125*b0 + 7154*b1 + 721*b2 (k_threshold.hip)
     hipEvent_t passes_event; // recorded on the launch stream right after the histogram pass (lfa_stream_wait_passes); may be null
     hipEvent_t wait_event;   // the image passes of this call start after it (lfa_chain_passes); may be null
-    uint32_t* plane_stats;   // [kStatsWords]  [12] 0x7fffffff - smallest and [13] largest integer mask threshold G_thr of the call's colour uint8 images, [14] images the
-                             //      predicted-threshold plane was written for, [15] those whose mask was decided from it (k_otsu_rgb); [11] colour images of this call with three equal channels throughout; [4] longest analysis window of the call in rows (k_finalize); [0] colour images of this call whose mask could be decided from the class plane, [1] colour images
+    uint32_t* plane_stats;   // [kStatsWords]  [12] 0x7fffffff - smallest and [13] largest integer mask threshold of the call's images (colour uint8: G_thr,
+                             //      k_otsu_rgb; uint16 frames on the one-pass histogram: T = x_thr + 1 of the frames with few pixels near it, k_otsu_int),
+                             //      [14] images the predicted-threshold plane was written for, [15] those whose mask was decided from it; [16] uint16 frames the
+                             //      handle's candidate window (pred_probe_lo / _hi) would have held, [17] frames that was looked at; [11] colour images of this call with three equal channels throughout; [4] longest analysis window of the call in rows (k_finalize); [0] colour images of this call whose mask could be decided from the class plane, [1] colour images
                              //      seen (k_otsu_rgb counts), [2] largest pixel value of the call's uint16 images, [3] uint16 images
                              //      seen (k_otsu_int); [5] sum, [8] number, [9] 65535 - smallest and [10] largest of the uint16 thresholds x_thr, [6] uint16 images whose
                              //      mask could be decided from the class plane around u16_pa, [7] images that test was made on;
@@ -99,6 +101,8 @@ struct Job {
     uint8_t* grey_plane;     // grey mode: [n][grey_plane_stride] channel 0 of every pixel, written by k_grey_hist and compared by k_mask instead of
     int64_t grey_plane_stride;   //         the three channels (1 byte per pixel instead of 3).  Lives in the `bbox` buffer, which nothing uses before
                              //         the labelling stage; null when that buffer is smaller than H*W bytes per image (line_length > 15)
+    // (uint16 frames, one-pass histogram: the same with the pixel value in place of G and T = x_thr + 1 in place of G_thr -- the mask is
+    // `pixel >= T` --, any window ends; k_hist_u16 writes the bits and the list, k_otsu_int decides.)
     // Predicted-threshold mode (colour uint8 images, vector path): the handle's last completed call gives a window [pred_lo, pred_hi] -- both
     // multiples of 1024, the bucket size of k_hist_rgb's table -- in which this call's integer mask thresholds G_thr are expected.  k_hist_rgb
     // then writes ONE bit per pixel, G >= pred_hi, into `bins` instead of the 4-bit class, and appends the 16-pixel groups holding a pixel with
@@ -110,6 +114,9 @@ struct Job {
     uint32_t* pred_list;     // [n][pred_stride] indices of the listed groups; lives in the `bbox` buffer like grey_plane
     int64_t pred_stride;
     int32_t pred_cap;        // entries an image may use
+    uint32_t* thr_list;      // [n] uint16, one-pass histogram: T = x_thr + 1 of every frame with few pixels near it, else 0 (k_otsu_int) -> the handle's next window
+    uint32_t pred_probe_lo, pred_probe_hi;   // uint16, one-pass histogram: the window the handle would use next -- k_otsu_int reports how many
+                             //         frames of this call it would have held (plane_stats[16], [17]); hi <= lo: none
     const double* host_pow;  // [n] LfaHostPow records (lfa_set_host_pow) or null: vmin, vmax, 257 gray-space edges, 256 gray-space thresholds
     const uint8_t* lut8;     // [256]
     const uint16_t* lut16;   // [65536]

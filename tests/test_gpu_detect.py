@@ -307,7 +307,7 @@ def test_uint16_class_plane_paths_agree(capi, W):
     try:
         batch = np.stack([_u16_separated(rng, W=W), _u16_frame(rng, 4095, W=W), _u16_separated(rng, W=W, noise=True)])
         for flags in (16 | 4, 16 | 4, 16 | 4, 16 | 2, 16):
-            eng.set_debug_flags(flags)
+            eng.set_debug_flags(flags | 8192)               # (8192: not the predicted-threshold bit plane -- this test is about the class plane)
             res = eng.detect(batch, 60, 10)
             for i in range(len(batch)):
                 check_detect(capi, eng, batch[i], 60, 10, batch_index=i, res=res)
@@ -326,6 +326,7 @@ def test_uint16_class_plane_is_chosen_per_image_and_per_call(capi):
     written while at least half of the last call's frames could use it.  The test carries a host model of those rules."""
     rng = np.random.default_rng(22)
     eng = capi.Engine(device=0, max_h=160, max_w=256, max_batch=2)
+    eng.set_debug_flags(8192)                               # (not the predicted-threshold bit plane, which takes the class plane's place)
     st = {"one_pass": False, "have_pred": False, "plane_on": True, "mean": 0, "max": 65535, "spread": 0}
     seen = set()
     try:
@@ -404,7 +405,7 @@ def test_uint16_series_with_a_stable_threshold(capi):
     try:
         used = []
         for call in range(4):
-            res = eng.detect(series, 60, 10)
+            res = eng.detect(series, 60, 10)                        # (threshold inside the noise: the handle does not try the bit plane)
             for i in range(3):
                 check_detect(capi, eng, series[i], 60, 10, batch_index=i, res=res)
             used.append([eng.debug_used_plane(i) for i in range(3)])
@@ -622,7 +623,7 @@ def test_random_small_images_against_oracle(capi, eng, seed):
         mm_r, mm_c = int(rng.integers(0, max(1, H))), int(rng.integers(0, max(1, W // 2 + 1)))
         # colour: default choice of the class plane, or forced; uint16: default, or one-pass histogram with the plane forced
         # (its classes centred on whatever threshold the shared handle met last), or the two-pass histogram
-        eng.set_debug_flags(int(rng.choice([0, 4, 0, 1024, 1024 | 1, 1024 | 4096, 8192, 16384, 32768, 32768 | 1])) if kind == 2 else (int(rng.choice([0, 16 | 4, 8])) if kind == 1 else 0))
+        eng.set_debug_flags(int(rng.choice([0, 4, 0, 1024, 1024 | 1, 1024 | 4096, 8192, 16384, 32768, 32768 | 1])) if kind == 2 else (int(rng.choice([0, 16 | 4, 8, 16 | 32768, 16 | 8192, 16 | 16384])) if kind == 1 else 0))
         try:
             check_detect(capi, eng, arr, mm_r, mm_c, L)
         finally:
@@ -937,3 +938,57 @@ def test_predicted_threshold_mode_in_analyze_batch_and_across_shapes(capi):
         assert all(took[1]) and not any(took[0])
     finally:
         e.close()
+
+
+def test_predicted_threshold_mode_on_uint16_frames(capi):
+    """uint16 frames on the one-pass histogram take the predicted-threshold mode too (pixel value in place of G, T = x_thr + 1): one bit
+    per pixel against the window of the last call's thresholds instead of the 4-bit class plane, undecided groups listed.  The handle
+    tries only while the window would have held at least half of the last call's frames; every intermediate equals the oracle whichever way."""
+    rng = np.random.default_rng(31)
+    eng = capi.Engine(device=0, max_h=160, max_w=256, max_batch=3)
+    try:
+        sep = np.stack([_u16_separated(rng) for _ in range(3)])
+        soft = sep.copy()                                            # blurred strip edges: pixels inside the window (few enough
+        for k in range(3):                                           # near the threshold for the handle to try: 1/1024 of 40 960)
+            a = soft[k].astype(np.float64)
+            soft[k] = ((a + np.roll(a, 1, axis=1)) / 2).astype(np.uint16)
+        noisy = np.stack([_u16_separated(rng, noise=True) for _ in range(3)])
+        bright = np.ascontiguousarray(np.minimum(sep.astype(np.int64) * 3, 16000).astype(np.uint16))     # thresholds elsewhere
+
+        def run(batch, L=10):
+            res = eng.detect(batch, 60, 10, L)
+            for i in range(len(batch)):
+                check_detect(capi, eng, batch[i], 60, 10, L, batch_index=i, res=res)
+            return [eng.debug_pred_path(i) for i in range(len(batch))]
+        assert run(sep) == [False] * 3                   # two-pass histogram
+        assert run(sep) == [False] * 3                   # one pass: this call reports its thresholds
+        assert run(sep) == [False] * 3                   # this one how many frames the window made of them would have held
+        assert run(sep) == [True] * 3
+        eng.close()
+        eng = capi.Engine(device=0, max_h=160, max_w=256, max_batch=3)
+        run(soft); run(soft); run(soft)
+        assert run(soft) == [True] * 3                   # pixels inside the window, decided through the list
+        assert run(bright) == [False] * 3                # another scene: every frame is compared on the frame itself
+        for _ in range(8):
+            assert run(bright) == [False] * 3            # ... and the handle stays out of the mode for eight calls
+        assert run(bright) == [True] * 3
+        mixed = np.stack([bright[0], sep[0], bright[1]])
+        assert run(mixed) == [True, False, True]         # per image
+        run(noisy); run(noisy)
+        assert run(noisy) == [False] * 3                 # thresholds inside the noise: not tried
+        eng.set_debug_flags(16 | 32768)                  # every pixel inside the window: each one goes through the list
+        assert run(sep) == [True] * 3
+        eng.set_debug_flags(8192)
+        assert run(sep) == [False] * 3
+        eng.set_debug_flags(0)
+    finally:
+        eng.close()
+    eng = capi.Engine(device=0, max_h=400, max_w=256, max_batch=2)
+    try:
+        tall = np.stack([_u16_separated(rng, H=400) for _ in range(2)])
+        eng.set_debug_flags(16 | 32768)
+        assert run(tall) == [True] * 2
+        assert run(tall, L=300) == [False] * 2           # the list lives in a buffer sized by line_length: it overflows, compare on the frame
+        eng.set_debug_flags(0)
+    finally:
+        eng.close()
