@@ -296,6 +296,7 @@ def main():
     for e in engs:
         e.timing(None)
 
+    pred_mode_seen = bool(engs[0].debug_pred_path(0))      # the last call's first image took its mask from the predicted-threshold bit plane
     # ---- results of one step; the final gather of the per-strip records (the path's only collective) ----
     inf = capi.from_device(info, capi.INFO_DT, B)
     assert (inf["status"] == 0).all(), "strip capacity overflow"
@@ -341,12 +342,14 @@ def main():
             # on nothing: they are latency-bound and never dominant)
             # SURVEY.md 8(d) prices S1+S2 (gray / gamma / histogram) at N*C*s bytes READ: that is `frac`.  What the kernel
             # additionally writes by this implementation's own choice (k_hist_rgb: the 4-bit class plane, N/2 bytes) is
-            # reported beside it as `frac_with_plane_store`, never inside `frac`.
+            # reported beside it as `frac_with_plane_store`, never inside `frac`.  (Settled handles write ONE bit per pixel -- the
+            # predicted-threshold plane, N/8 bytes -- and `plane_store_bytes_per_launch` says which plane this run wrote.)
             npx = H * W
             per_image = {"k_minmax_rgb": npx * 3,                 # image in
                          "k_hist_rgb": npx * 3,                    # image in
                          "k_mask": npx // 2 + npx // 8}.get(dominant, img_bytes)   # class plane in, bit mask out
-            own_store = {"k_hist_rgb": npx // 2}.get(dominant, 0)  # class plane out (4 bits per pixel)
+            # plane out: one bit per pixel in the predicted-threshold mode (what the settled handles of this run write), else the 4-bit class plane
+            own_store = {"k_hist_rgb": npx // 8 if pred_mode_seen else npx // 2}.get(dominant, 0)
             alg_bytes = CH * per_image
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             traffic, traffic_source = None, None
@@ -361,6 +364,7 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
                     "frac_with_plane_store": round((alg_bytes + CH * own_store) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "plane_store_bytes_per_launch": CH * own_store,
                     "note": (f"timed region: {NS} lanes, the image passes of consecutive chunks chained (lfa_chain_passes), so a launch of "
                              "this kernel has the chip to itself but for the tail kernels of the chunks before; "
                              if NS > 1 and args.stagger == 2 else

@@ -197,7 +197,12 @@ int lfa_set_host_pow(LfaHandle h, const LfaHostPow* tables, int n);
  * -- instead of the 4-bit class, and lists the 16-pixel groups holding a pixel inside the window; an image whose threshold
  * falls inside the window, with at most 1/16 of its groups listed, takes its mask from those bits plus an exact compare of
  * the listed pixels, any other image is compared on the image itself; a handle leaves the mode for eight calls when fewer
- * than half of a call's images could use their bits.  Results are identical either way.
+ * than half of a call's images could use their bits.  uint16 frames on the one-pass histogram take the same mode with the
+ * pixel value in place of G (T = x_thr + 1, the mask is `pixel >= T`): the window is the tightest cluster of the last call's
+ * T values -- the largest set within 32 values of each other, among the frames with few pixels near their threshold --
+ * widened by max(4, its range) either way, and the handle tries it only after a call has reported that the window would
+ * have held at least half of its frames (T inside it, at most 1/2048 of the pixels inside it); bit13 / bit14 / bit15 act
+ * on it as on the colour mode.  Results are identical either way.
  * bit8 (256) / bit9 (512): k_edges_rgb moves every interior gray-space histogram edge it computed one double up / down --
  * what a pow() whose last bit differs would do -- so that the tests can show an image with a pixel exactly on an edge
  * going wrong without lfa_set_host_pow and right with it (tables from lfa_set_host_pow are never touched). */

@@ -310,3 +310,25 @@ def test_host_pow_tables_reproduce_the_reference_histogram_and_mask(capi):
             assert np.array_equal(g >= thr_g[b], v > centres[b]), b
     const = capi.host_pow_tables(0.25, 0.25)                       # all-equal image: edge 0 = gmin, everything else unreachable
     assert const[0] == const[1] and const[2] == 0.25 and np.isinf(const[3:]).all()
+
+
+def test_minmax_screen_bound_holds_for_every_byte_triple():
+    """k_minmax_rgb screens pixels with g = 76*b0 + 255*b1 + 26*b2 (one v_dot4) instead of the exact integer gray
+    G = 2125*b0 + 7154*b1 + 721*b2 and relies on 28*g - 2550 <= G <= 28*g + 3570: a pixel with G <= Wlo has g <= (Wlo + 2550) // 28,
+    one with G >= Whi has g >= ceil((Whi - 3570) / 28).  Checked over all 2^24 triples (as the extreme values of a linear form
+    and by brute force on a slice), together with the two screening inequalities on random bounds."""
+    assert (2125 - 28 * 76, 7154 - 28 * 255, 721 - 28 * 26) == (-3, 14, -7)
+    assert -3 * 255 - 7 * 255 == -2550 and 14 * 255 == 3570
+    b = np.arange(256, dtype=np.int64)
+    for b0 in (0, 1, 127, 254, 255):
+        G = 2125 * b0 + 7154 * b[:, None] + 721 * b[None, :]
+        g = 76 * b0 + 255 * b[:, None] + 26 * b[None, :]
+        assert ((28 * g - 2550 <= G) & (G <= 28 * g + 3570)).all()
+    rng = np.random.default_rng(5)
+    t = rng.integers(0, 256, size=(200000, 3))
+    G = 2125 * t[:, 0] + 7154 * t[:, 1] + 721 * t[:, 2]
+    g = 76 * t[:, 0] + 255 * t[:, 1] + 26 * t[:, 2]
+    for Wlo, Whi in rng.integers(0, 2550001, size=(50, 2)):
+        Alo = (Wlo + 2550) // 28
+        Ahi = (Whi - 3570 + 27) // 28 if Whi > 3570 else 0
+        assert (g[G <= Wlo] <= Alo).all() and (g[G >= Whi] >= Ahi).all()

@@ -23,7 +23,7 @@ run_stats cfg4 $R/benchmarks_configs.py rois && echo stats cfg4 ok &&
 run_stats photo $R/benchmarks_configs.py photo && echo stats photo ok &&
 run_stats gauss $R/benchmarks_configs.py gauss && echo stats gauss ok &&
 run_stats lines $R/benchmarks_configs.py lines && echo stats lines ok &&
-run_pmc bench FETCH_SIZE $HEAD --batch 1024 --steps 1 --warmup 1 && run_pmc bench WRITE_SIZE $HEAD --batch 1024 --steps 1 --warmup 1 && echo pmc bench ok &&
+run_pmc bench FETCH_SIZE $HEAD --batch 1024 --steps 1 --warmup 3 && run_pmc bench WRITE_SIZE $HEAD --batch 1024 --steps 1 --warmup 3 && echo pmc bench ok &&
 run_pmc cfg2 FETCH_SIZE $R/benchmarks_configs.py u16 && run_pmc cfg2 WRITE_SIZE $R/benchmarks_configs.py u16 && echo pmc cfg2 ok &&
 run_pmc photo FETCH_SIZE $R/benchmarks_configs.py photo && run_pmc photo WRITE_SIZE $R/benchmarks_configs.py photo && echo pmc photo ok &&
 run_pmc cfg4 FETCH_SIZE $R/benchmarks_configs.py rois && run_pmc cfg4 WRITE_SIZE $R/benchmarks_configs.py rois && echo pmc cfg4 ok &&

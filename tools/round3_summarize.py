@@ -16,7 +16,7 @@ import sys
 
 SRC = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r03"
 DST = sys.argv[2] if len(sys.argv) > 2 else "profiles"
-CMD = {"bench": "bench.py --cpu-sample 0 --no-configs (stats; the default schedule only, its JSON line in r03_bench_under_rocprof.json) / ... --no-kernel-timing --batch 1024 --steps 1 --warmup 1 (pmc)",
+CMD = {"bench": "bench.py --cpu-sample 0 --no-configs (stats; the default schedule only, its JSON line in r03_bench_under_rocprof.json) / ... --no-kernel-timing --batch 1024 --steps 1 --warmup 3 (pmc)",
        "cfg2": "benchmarks_configs.py u16", "cfg3": "benchmarks_configs.py big", "cfg4": "benchmarks_configs.py rois", "photo": "benchmarks_configs.py photo",
        "gauss": "benchmarks_configs.py gauss", "lines": "benchmarks_configs.py lines"}
 
@@ -53,13 +53,15 @@ def per_kernel(path):
         k = short(r["Kernel_Name"])
         if k:
             acc[k].append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+    # median over the launches: the first calls of a handle take other paths (no plane yet, then the class plane) than the
+    # settled ones (predicted-threshold bit plane), and the settled launches are the majority of a run with three warm-up steps
+    return {k: (sorted(v)[len(v) // 2], len(v)) for k, v in acc.items()}
 
 
 traffic = {"_source": "profiles/r03_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs of "
-                      "bench.py --batch 1024 --chunk 256 --steps 1 --warmup 1; tools/round3_profile.sh)"}
+                      "bench.py --batch 1024 --chunk 256 --steps 1 --warmup 3; tools/round3_profile.sh; median over a kernel's launches)"}
 with open(f"{DST}/r03_pmc_hbm_traffic.csv", "w") as fo:
-    fo.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one counter per run (tools/round3_profile.sh); mean over the launches of a kernel\n")
+    fo.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, one counter per run (tools/round3_profile.sh); median over the launches of a kernel\n")
     fo.write("# hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (KiB units; gfx950 FETCH_SIZE tallies each 128-byte line request at 64 bytes: calibrated for\n")
     fo.write("# coalesced streaming reads by MI355X_MICROARCH.md and for scattered 16..64-byte pieces by tools/scatter_probe.hip, profiles/r03_scatter_probe.csv -- every row below)\n")
     fo.write("config,command,kernel,launches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes_per_launch\n")
