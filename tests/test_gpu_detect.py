@@ -49,8 +49,8 @@ def check_detect(capi, eng, image, mm_r, mm_c, L=10, batch_index=0, res=None):
     assert inf["ambiguous"] == 0 or (inf["status"] & 4)
     thr = capi.host_threshold(inf, colour)
     assert thr == d["threshold"], (thr, d["threshold"])
-    if (inf["status"] & 4) and len(info) > 1:
-        # the handle's last call was the host-pow run of a sub-batch: the intermediates of this image are not at batch_index
+    if len(info) > 1 and (np.asarray(info["status"]) & 4).any():
+        # the handle's last call was the host-pow run of a sub-batch: the intermediates of this batch's images are not at batch_index
         got = [[int(s["minr"]), int(s["maxr"]), int(s["minc"]), int(s["maxc"])] for s in strips[batch_index]]
         assert got == d["strips"] and inf["n_labels"] == d["n_labels"]
         return d

@@ -37,3 +37,7 @@ def test_static_entry_point_sequence_against_analyze_batch():
 
 def test_scalar_float64_paths_over_more_seeds():
     _tool("dtype_fuzz").run(12)
+
+
+def test_drifting_series_through_the_predicted_threshold_mode():
+    _tool("series_fuzz").run(150, 3)           # colour and uint16 frames of a drifting scene, other scenes mixed in (bit plane / list / fallback / back-off)
