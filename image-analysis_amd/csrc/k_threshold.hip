@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void k_edges_rgb(Job j) {
     __shared__ double s_t[kEdges];
     __shared__ uint32_t s_nh[256];
     const bool grey = j.grey_mode && egf[kEdgesI_Grey] != 0u;
+    if (j.grey_mode && j.pred_mode && !grey && threadIdx.x == 0) egf[kEdgesI_PredCnt] = 0u;   // k_hist_rgb lists this image's groups itself
     if (j.grey_mode) {
         uint32_t* gh = j.hist + (int64_t)img * j.hist_stride;
         if (threadIdx.x == 0) { s_b[0] = 255; s_b[1] = 0; }
@@ -283,8 +284,17 @@ __global__ __launch_bounds__(256) void k_grey_hist(Job j) {
     // compiler-placed waits (vmcnt(0) at the boundary: the store's round trip included) the pass took 0.63 ms per 256
     // images instead of 0.37 without a plane.  Every round has lane 0 inside the image, so the store is one operation of the
     // wave in every round, which the counted wait relies on.
-    auto pass = [&](auto plane) {
-        constexpr bool kPlane = decltype(plane)::value;
+    // kind 0: byte histogram only; 1: also the byte plane; 2: also the predicted-threshold bit plane and the list of undecided groups
+    // (Job::pred_mode, as k_hist_rgb writes them: a grey pixel has G = 10000 * b, so `G >= hi` is `b >= ceil(hi / 10000)` -- against the
+    // window's ends before they were widened to whole buckets, pred_lo_raw / pred_hi_raw; an image that turns out not to be grey gets
+    // its bits from k_hist_rgb instead, k_edges_rgb drops what this pass listed for it)
+    uint16_t* pbits = (uint16_t*)(j.bins + (int64_t)img * (((int64_t)j.H * j.W) >> 3));
+    uint32_t* pcnt = j.edges_i + (int64_t)img * kEdgesI + kEdgesI_PredCnt;
+    uint32_t* plist = j.pred_list + (int64_t)img * j.pred_stride;
+    const uint32_t pcap = (uint32_t)j.pred_cap, b_lo = (j.pred_lo_raw + 9999u) / 10000u, b_hi = (j.pred_hi_raw + 9999u) / 10000u;
+    auto pass = [&](auto kind) {
+        constexpr int kKind = decltype(kind)::value;
+        constexpr bool kPlane = kKind != 0;
         Raw48 nx;
         int64_t r = (int64_t)blockIdx.x * per_block + wv4;
         if (r >= r_end) return;
@@ -304,7 +314,26 @@ __global__ __launch_bounds__(256) void k_grey_hist(Job j) {
                 notgrey |= not_grey16(w);
 #pragma unroll
                 for (int k = 0; k < 16; ++k) atomicAdd(&shl[byte_of(w, 3 * k) * kHC], 1u);
-                if (kPlane) {
+                if (kKind == 2) {
+                    uint32_t set = 0, und = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const uint32_t b = byte_of(w, 3 * k);
+                        set |= (b >= b_hi ? 1u : 0u) << k;
+                        und |= (b >= b_lo && b < b_hi) ? 1u : 0u;
+                    }
+                    const unsigned long long um = __ballot(und != 0u);   // (over the lanes inside the image)
+                    if (um) {
+                        const int leader = __ffsll(um) - 1;
+                        uint32_t slot0 = 0;
+                        if (lane == leader) slot0 = atomicAdd(pcnt, (uint32_t)__popcll(um));
+                        slot0 = (uint32_t)__shfl((int)slot0, leader);
+                        const uint32_t slot = slot0 + (uint32_t)__popcll(um & ((1ull << lane) - 1ull));
+                        if (und != 0u && slot < pcap) plist[slot] = (uint32_t)(r * 64 + lane);
+                    }
+                    vm_store2(pbits + (r * 64 + lane), set);
+                }
+                if (kKind == 1) {
                     // channel 0 of the 16 pixels: stream bytes 0, 3, 6, ... -- two v_perm per four pixels -- as one 16-byte store
                     lfa_u32x4 o;
                     uint32_t t;
@@ -318,7 +347,9 @@ __global__ __launch_bounds__(256) void k_grey_hist(Job j) {
             vm_wait48<kPlane ? 1 : 0>(nx);
         }
     };
-    if (gplane) pass(std::true_type{}); else pass(std::false_type{});
+    if (j.pred_mode && j.bins) pass(std::integral_constant<int, 2>{});
+    else if (gplane) pass(std::integral_constant<int, 1>{});
+    else pass(std::integral_constant<int, 0>{});
     __syncthreads();
     uint32_t tot = 0;
 #pragma unroll
@@ -1136,7 +1167,11 @@ __global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
     const bool exact = eg[kEdgesI_Crit] == 0 && !crit && !(j.debug_flags & 1) && j.dtype == LFA_U8 && G_thr < 0x400000u;
     if (exact && j.plane_stats) { atomicMax(&j.plane_stats[12], 0x7fffffffu - G_thr); atomicMax(&j.plane_stats[13], G_thr); }
     if (j.pred_mode) {
-        const bool held = exact && G_thr >= j.pred_lo && G_thr <= j.pred_hi && eg[kEdgesI_PredCnt] <= (uint32_t)j.pred_cap;
+        // (an equal-channel image of a grey-mode call: k_grey_hist wrote its bits, in grey levels against the unwidened window)
+        const uint32_t b_thr = (G_thr + 9999u) / 10000u;
+        const bool inside = (j.grey_mode && is_grey) ? (b_thr >= (j.pred_lo_raw + 9999u) / 10000u && b_thr <= (j.pred_hi_raw + 9999u) / 10000u)
+                                                     : (G_thr >= j.pred_lo && G_thr <= j.pred_hi);
+        const bool held = exact && inside && eg[kEdgesI_PredCnt] <= (uint32_t)j.pred_cap;
         eg[kEdgesI_Bins] = held ? 2u : 0u;
         if (j.plane_stats) { atomicAdd(&j.plane_stats[14], 1u); if (held) atomicAdd(&j.plane_stats[15], 1u); }
     }

@@ -163,7 +163,7 @@ struct LfaContext {
     // widened by 16384 (of G's 2 550 000 steps: a grey level and a half, about one histogram bin in mid-range) on either side.  When fewer than half of the images of a call in
     // the mode could use their bit plane (another scene, or too many pixels inside the window), the next eight calls go without.
     bool pred_have = false, pending_pred = false;
-    uint32_t pred_lo = 0, pred_hi = 0;
+    uint32_t pred_lo = 0, pred_hi = 0, pred_lo_raw = 0, pred_hi_raw = 0;      // (_raw: the range without the margin)
     int pred_backoff = 0;
     // (uint16 frames on the one-pass histogram take the same mode with the pixel value in place of G: the window is the range of T = x_thr + 1
     // of the last completed call widened by max(4, that range) either way, and the handle tries only while at least half of that call's frames
@@ -343,15 +343,23 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
     const bool rgb_plane = C == 3 && dtype == LFA_U8 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & 2) && (h->plane_on || (h->debug_flags & 4));
     // predicted-threshold bit plane instead of the class plane (debug flag 8192: never; 32768: always, with a window that holds every
     // threshold and a list that holds every group -- each pixel then goes through k_mask_fix)
-    const bool pred_shape = C == 3 && dtype == LFA_U8 && j.aligned16 && (W % 16) == 0 && !j.grey_mode && !(h->debug_flags & (2 | 8192)) &&
+    const bool pred_shape = C == 3 && dtype == LFA_U8 && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & (2 | 8192)) &&
                             w.bins.bytes >= (size_t)n * (((size_t)H * W + 1) / 2);
     const int64_t groups = (int64_t)H * W / 16, room = (int64_t)j.run_cap * 4;     // (the list's home holds 16 bytes per run slot)
     if (pred_shape && (h->debug_flags & 32768)) {
-        j.pred_mode = 1; j.pred_lo = 0u; j.pred_hi = 0x400000u;
+        j.pred_mode = 1; j.pred_lo = 0u; j.pred_hi = 0x400000u; j.pred_lo_raw = 0u; j.pred_hi_raw = 0x400000u;
         j.pred_cap = (int32_t)(groups < room ? groups : room);
     } else if (pred_shape && h->pred_have && h->pred_kind == 2 && h->pred_backoff == 0) {
         j.pred_mode = 1; j.pred_lo = h->pred_lo & ~1023u; j.pred_hi = (h->pred_hi + 1023u) & ~1023u;      // whole buckets of k_hist_rgb's table
         j.pred_cap = (int32_t)(groups / 16 < room ? groups / 16 : room);
+        if (j.grey_mode) {
+            // Grey mode: the thresholds of equal-channel images move in steps of a grey level (G = 10000 * b) and sit on populated levels,
+            // so a margin would put whole grey levels on the list.  The window is the last call's range as it is -- a series with one
+            // byte threshold then has no undecided pixel at all (k_grey_hist writes `b >= b_thr` and the mask pass reads 1/8 byte per
+            // pixel instead of the byte plane's 1) -- and any other series falls back, at what the byte-plane path costs.
+            j.pred_lo = (h->pred_lo_raw) & ~1023u; j.pred_hi = (h->pred_hi_raw + 1023u) & ~1023u;
+            j.pred_lo_raw = h->pred_lo_raw; j.pred_hi_raw = h->pred_hi_raw;
+        }
     }
     const bool pred_shape_u16 = C == 1 && dtype == LFA_U16 && j.hist_abs && j.aligned16 && (W % 16) == 0 && !(h->debug_flags & (2 | 8192)) &&
                                 w.bins.bytes >= (size_t)n * (((size_t)H * W + 1) / 2);
@@ -391,7 +399,7 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
     j.rowsum_cap = 16 * H;
     j.slot_rs_off = (int32_t*)w.slot_rs_off.p;
     j.grey_plane_stride = (int64_t)j.run_cap * 16;
-    j.grey_plane = (j.grey_mode && j.grey_plane_stride >= (int64_t)H * W && !(h->debug_flags & 4096)) ? (uint8_t*)w.bbox.p : nullptr;
+    j.grey_plane = (j.grey_mode && !j.pred_mode && j.grey_plane_stride >= (int64_t)H * W && !(h->debug_flags & 4096)) ? (uint8_t*)w.bbox.p : nullptr;   // (pred_mode: the list lives there)
     j.lut8 = (const uint8_t*)h->lut8.p;
     j.lut16 = (const uint16_t*)h->lut16.p;
     return j;
@@ -477,6 +485,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
                 const uint32_t margin = (h->debug_flags & 16384) ? 0u : 16384u;
                 h->pred_lo = tmin > margin ? tmin - margin : 0u;
                 h->pred_hi = tmax + margin;
+                h->pred_lo_raw = tmin; h->pred_hi_raw = tmax;
             }
             h->pred_sparse = h->plane_host[17] != 0u && 2u * h->plane_host[16] >= h->plane_host[17];
             if (h->pending_pred && h->plane_host[14] && 2u * h->plane_host[15] < h->plane_host[14]) h->pred_backoff = 8;

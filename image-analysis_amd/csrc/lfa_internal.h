@@ -114,6 +114,8 @@ struct Job {
     uint32_t* pred_list;     // [n][pred_stride] indices of the listed groups; lives in the `bbox` buffer like grey_plane
     int64_t pred_stride;
     int32_t pred_cap;        // entries an image may use
+    uint32_t pred_lo_raw, pred_hi_raw;   // grey mode: the window before it was widened to whole buckets -- k_grey_hist works in grey levels
+                             //         (b_lo = ceil(pred_lo_raw / 10000), b_hi likewise), and a bucket edge must not pull a whole level onto the list
     uint32_t* thr_list;      // [n] uint16, one-pass histogram: T = x_thr + 1 of every frame with few pixels near it, else 0 (k_otsu_int) -> the handle's next window
     uint32_t pred_probe_lo, pred_probe_hi;   // uint16, one-pass histogram: the window the handle would use next -- k_otsu_int reports how many
                              //         frames of this call it would have held (plane_stats[16], [17]); hi <= lo: none

@@ -202,7 +202,9 @@ int lfa_set_host_pow(LfaHandle h, const LfaHostPow* tables, int n);
  * T values -- the largest set within 32 values of each other, among the frames with few pixels near their threshold --
  * widened by max(4, its range) either way, and the handle tries it only after a call has reported that the window would
  * have held at least half of its frames (T inside it, at most 1/2048 of the pixels inside it); bit13 / bit14 / bit15 act
- * on it as on the colour mode.  Results are identical either way.
+ * on it as on the colour mode.  Equal-channel images in grey mode (bit10 / the handle's own finding): the window is the
+ * last call's range of thresholds as it is, in grey levels -- no margin: a series with one byte threshold has no undecided
+ * pixel, any other falls back per image.  Results are identical either way.
  * bit8 (256) / bit9 (512): k_edges_rgb moves every interior gray-space histogram edge it computed one double up / down --
  * what a pow() whose last bit differs would do -- so that the tests can show an image with a pixel exactly on an edge
  * going wrong without lfa_set_host_pow and right with it (tables from lfa_set_host_pow are never touched). */

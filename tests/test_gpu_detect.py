@@ -992,3 +992,43 @@ def test_predicted_threshold_mode_on_uint16_frames(capi):
         eng.set_debug_flags(0)
     finally:
         eng.close()
+
+
+def test_predicted_threshold_mode_on_equal_channel_images(capi, golden_dir):
+    """Grey mode + predicted-threshold mode: k_grey_hist writes the bits itself, in grey levels (G = 10000 * b) against the last call's
+    range of thresholds WITHOUT margin or bucket rounding -- a series with one byte threshold has no undecided pixel, any other
+    series falls back per image.  Checked: identical thresholds (rolled copies: bits hold, even when a multiple of 10000 lies
+    beside the threshold), a brighter copy (other threshold: compare on the image), a colour image and an almost-grey image inside
+    the call (k_hist_rgb writes their bits and lists), every pixel through the list (forced), the float64 compare path."""
+    from image_analysis_amd.synth import synth_rgb
+    g = np.load(os.path.join(golden_dir, "image1_decoded.npz"))["gray"][:192, :256]
+    H, W = g.shape
+    greys = np.stack([np.repeat(np.roll(g, 7 * k, axis=1)[:, :, None], 3, axis=2) for k in range(3)])
+    brighter = np.ascontiguousarray(np.minimum(greys.astype(np.int32) + 40, 255).astype(np.uint8))
+    colour = synth_rgb(H, W, 4, 30)
+    almost = greys[1].copy(); almost[-1, -1, 2] ^= 1
+    mm_r, mm_c = gui_params(g)
+    e = capi.Engine(device=0, max_h=H, max_w=W, max_batch=3)
+    try:
+        def run(batch):
+            res = e.detect(batch, mm_r, mm_c)
+            for i in range(len(batch)):
+                check_detect(capi, e, batch[i], mm_r, mm_c, batch_index=i, res=res)
+            return [e.debug_grey_path(i) for i in range(len(batch))], [e.debug_pred_path(i) for i in range(len(batch))]
+        assert run(greys) == ([False] * 3, [False] * 3)          # ordinary passes; they count the grey images and report the thresholds
+        assert run(greys) == ([True] * 3, [True] * 3)            # grey mode, and the bits hold: one threshold, no undecided pixel
+        assert run(greys) == ([True] * 3, [True] * 3)
+        mixed = np.stack([greys[0], colour, almost])
+        grey_path, pred_path = run(mixed)
+        assert grey_path == [True, False, False] and pred_path[0]  # the colour and the almost-grey image: k_hist_rgb's bits, or the image
+        assert run(brighter)[1] == [False] * 3                   # other thresholds: every image compared on the image itself
+        e.set_debug_flags(1024 | 32768)                          # grey mode and every pixel through the list
+        assert run(greys) == ([True] * 3, [True] * 3)
+        assert run(mixed)[1] == [True] * 3
+        e.set_debug_flags(1024 | 32768 | 1)                      # float64 compare path: no integer threshold, no bits
+        assert run(greys)[1] == [False] * 3
+        e.set_debug_flags(1024 | 8192)
+        assert run(greys) == ([True] * 3, [False] * 3)
+        e.set_debug_flags(0)
+    finally:
+        e.close()

@@ -25,8 +25,9 @@ def _load(path, name):
 
 
 def scene_frame(rng, H, W, kind, p):
-    """one frame of scene p: dark noisy ground, a few bright strips with soft edges; kind 0 colour uint8, 1 uint16"""
-    top = 255.0 if kind == 0 else p["top"]
+    """one frame of scene p: dark noisy ground, a few bright strips with soft edges; kind 0 colour uint8, 1 uint16, 2 colour uint8 with
+    three equal channels (the handle's grey mode)"""
+    top = 255.0 if kind != 1 else p["top"]
     g = rng.normal(p["bg"] * top, p["noise"] * top, size=(H, W))
     for c0, w in p["strips"]:
         g[p["r0"]:p["r1"], c0:c0 + w] = rng.normal(p["fg"] * top, p["noise"] * top, size=(p["r1"] - p["r0"], w))
@@ -35,6 +36,9 @@ def scene_frame(rng, H, W, kind, p):
     g = np.clip(g, 0, top)
     if kind == 1:
         return g.astype(np.uint16)
+    if kind == 2:                                                  # three equal channels: what cv2.imread makes of a grey file
+        q = np.round(g / p["step"]) * p["step"] if p.get("step", 1) > 1 else g       # (coarse levels: thresholds then repeat from call to call)
+        return np.ascontiguousarray(np.repeat(np.clip(q, 0, 255).astype(np.uint8)[:, :, None], 3, axis=2))
     out = np.stack([g + rng.integers(-2, 3, size=g.shape) for _ in range(3)], axis=-1)
     return np.clip(out, 0, 255).astype(np.uint8)
 
@@ -45,7 +49,7 @@ def new_scene(rng, H, W, kind):
     r0 = int(rng.integers(0, H // 3))
     return {"bg": float(rng.uniform(0.03, 0.35)), "fg": float(rng.uniform(0.5, 0.95)), "noise": float(rng.uniform(0.002, 0.04)),
             "soft": int(rng.integers(0, 3)), "strips": strips, "r0": r0, "r1": int(rng.integers(r0 + 20, H)),
-            "top": float(rng.choice([1023, 4095, 16383, 65535])) if kind == 1 else 255.0}
+            "top": float(rng.choice([1023, 4095, 16383, 65535])) if kind == 1 else 255.0, "step": int(rng.choice([1, 1, 8, 16]))}
 
 
 def drift(rng, p):
@@ -63,7 +67,7 @@ def run(calls, seed):
     rng = np.random.default_rng(seed)
     t0 = time.time()
     held = tried = frames = 0
-    for kind in (0, 1):
+    for kind in (0, 1, 2):
         H, W = int(rng.choice([96, 128, 160])), int(rng.choice([128, 192, 256]))
         eng = capi.Engine(device=0, max_h=H, max_w=W, max_c=3, max_batch=4)
         p = new_scene(rng, H, W, kind)
@@ -95,7 +99,7 @@ def run(calls, seed):
             if call % 100 == 0:
                 print(f"kind {kind} call {call} ok, {held} of {frames} frames decided from the bit plane, {time.time() - t0:.0f} s", flush=True)
         eng.close()
-    print(f"series fuzz ok: 2 x {calls} calls (seed {seed}), {frames} frames, {held} decided from the predicted-threshold bit plane, {time.time() - t0:.0f} s")
+    print(f"series fuzz ok: 3 x {calls} calls (seed {seed}), {frames} frames, {held} decided from the predicted-threshold bit plane, {time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
