@@ -1253,8 +1253,9 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
             LFA_LAUNCH("k_minmax_u16", k_minmax_u16, grid, dim3(256), 0, s, j);
             LFA_LAUNCH("k_zero_hist_u16", k_zero_hist_u16, dim3(16, j.n), dim3(256), 0, s, j);
         }
-        static const int u16_threads = [] { const char* e = getenv("LFA_U16_THREADS"); return e ? atoi(e) : 1024; }();
-        static const int u16_ppt = [] { const char* e = getenv("LFA_U16_PPT"); return e ? atoi(e) : 64; }();
+        // (tuning knobs of tools/r3_u16_block_sizes.sh: threads per block -- 256 / 512 / 768 measured within 2 % of 1024 or worse -- and pixels per thread)
+        static const int u16_threads = [] { const char* e = getenv("LFA_U16_THREADS"); const int v = e ? atoi(e) : 1024; return (v >= 256 && v <= 1024 && v % 64 == 0) ? v : 1024; }();
+        static const int u16_ppt = [] { const char* e = getenv("LFA_U16_PPT"); const int v = e ? atoi(e) : 64; return v >= 16 ? v : 64; }();
         const dim3 gridh(blocks_per_image(j, u16_threads * u16_ppt), j.n);
         if (j.pred_mode && j.bins) LFA_LAUNCH("k_hist_u16", k_hist_u16<2>, gridh, dim3(u16_threads), 0, s, j);
         else if (j.u16_plane && j.bins) LFA_LAUNCH("k_hist_u16", k_hist_u16<1>, gridh, dim3(u16_threads), 0, s, j);

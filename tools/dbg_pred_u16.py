@@ -1,3 +1,4 @@
+"""dev aid: per-kernel times and the way each frame of a uint16 batch is decided, call after call: python tools/dbg_pred_u16.py"""
 import numpy as np, sys, torch
 sys.path.insert(0, ".")
 import image_analysis_amd._capi as capi

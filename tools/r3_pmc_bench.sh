@@ -1,5 +1,5 @@
 #!/bin/bash
-# One rocprofv3 --pmc pass over the headline bench (kernels serialised by the profiler): tools/s4_pmc_bench.sh <tag> "<bench flags>" <counter> ...
+# One rocprofv3 --pmc pass over the headline bench (kernels serialised by the profiler): tools/r3_pmc_bench.sh <tag> "<bench flags>" <counter> ...
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 tag=$1; flags=$2; shift 2
 export TMPDIR=/tmp
