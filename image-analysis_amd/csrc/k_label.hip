@@ -48,12 +48,27 @@ __device__ inline uint64_t drop_short_runs(uint64_t w, uint64_t above, int L) {
     return w & keep;
 }
 
-// Walk column c of maskT top to bottom and call emit(start, end_inclusive) for every surviving run.
-template <class Emit>
-__device__ inline void column_runs(const uint64_t* colw, int HB, int H, int W, int L, const Emit& emit) {
+// 64 x 64 bit matrix across the wave: lane i comes in with row i (bit k = column k) and leaves with column i (bit k = row k).  Six
+// block swaps between lane pairs (i, i ^ s), s = 32 .. 1: the upper lane of a pair takes its odd s-blocks from the partner's even ones
+// and the lower lane the other way round.  ALL 64 lanes must be here.
+__device__ __forceinline__ uint64_t transpose_bits64(uint64_t w, int lane) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const uint64_t m0 = s == 32 ? 0x00000000ffffffffull : s == 16 ? 0x0000ffff0000ffffull : s == 8 ? 0x00ff00ff00ff00ffull
+                          : s == 4 ? 0x0f0f0f0f0f0f0f0full : s == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+        const uint64_t pw = __shfl_xor(w, s);
+        w = (lane & s) ? ((w & ~m0) | ((pw & ~m0) >> s)) : ((w & m0) | ((pw & m0) << s));
+    }
+    return w;
+}
+
+// Walk one column top to bottom -- word(rb) = its 64-row word of row block rb -- and call emit(start, end_inclusive) for every
+// surviving run.
+template <class Word, class Emit>
+__device__ inline void column_runs(const Word& word, int HB, int H, int L, const Emit& emit) {
     int start = -1;
     for (int rb = 0; rb < HB; ++rb) {
-        uint64_t w = colw[(int64_t)rb * W];
+        uint64_t w = word(rb);
         uint64_t t = w ^ ((w << 1) | (start >= 0 ? 1ull : 0ull));       // bit k set: mask changes between row k-1 and k
         if (__popcll((unsigned long long)t) > 8) {                       // a noisy word: most of its runs are too short to survive
             const int rem = H - rb * 64;
@@ -84,10 +99,30 @@ __global__ __launch_bounds__(256) void k_runs_count(Job j) {
     int n = 0;
     uint32_t* tmp = j.run_tmp + (int64_t)img * j.run_cap + (int64_t)c * j.runs_per_col;
     const int per = j.runs_per_col;
-    column_runs(j.maskT + (int64_t)img * j.HB * j.W + c, j.HB, j.H, j.W, j.line_length, [&](int s, int e) {
+    auto emit = [&](int s, int e) {
         if (n < per) tmp[n] = (uint32_t)s | ((uint32_t)e << 16);
         ++n;
-    });
+    };
+    if (j.pred_fused && j.edges_i[(int64_t)img * kEdgesI + kEdgesI_Bins] == 2u) {
+        // Predicted-threshold mode, widths that are multiples of 64: the mask is still the row-major bit plane of the histogram pass
+        // (k_mask left this image alone, k_mask_fix has set the listed pixels in it).  The wave owns 64 columns; per row block, lane i
+        // fetches the 64 bits of row i and the wave turns the 64 x 64 block, so that every lane holds its column's word -- what
+        // k_mask would have written and this kernel read back (1/8 byte per pixel each way).  The next block's rows travel meanwhile.
+        const int lane = threadIdx.x & 63, c0 = c & ~63, H = j.H;
+        const uint64_t* plane = (const uint64_t*)(j.bins + (int64_t)img * (((int64_t)H * j.W) >> 3));
+        const int64_t wpr = j.W >> 6;                               // 64-bit words per row
+        auto rows = [&](int rb) -> uint64_t { const int r = rb * 64 + lane; return (rb < j.HB && r < H) ? plane[(int64_t)r * wpr + (c0 >> 6)] : 0ull; };
+        uint64_t n1 = rows(0);
+        column_runs([&](int rb) -> uint64_t {
+                        const uint64_t cur = n1; n1 = rows(rb + 1);
+                        // (leaving the all-clear blocks -- most of an image -- unturned was measured slower: 0.50 against 0.34 ms per 1024 images)
+                        return transpose_bits64(cur, lane);
+                    }, j.HB, H, j.line_length, emit);
+    } else {
+        const uint64_t* colw = j.maskT + (int64_t)img * j.HB * j.W + c;
+        const int W = j.W;
+        column_runs([&](int rb) -> uint64_t { return colw[(int64_t)rb * W]; }, j.HB, j.H, j.line_length, emit);
+    }
     if (n > per) { n = per; atomicOr(&j.info[img].status, 2); }          // cannot happen: runs_per_col is an upper bound
     j.col_cnt[(int64_t)img * (j.W + 1) + c] = (uint32_t)n;
 }
@@ -368,6 +403,11 @@ __global__ void k_dbg_mask(Job j, int img, uint8_t* out) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (int64_t)j.H * j.W) return;
     const int r = (int)(p / j.W), c = (int)(p % j.W);
+    if (j.pred_fused && j.edges_i[(int64_t)img * kEdgesI + kEdgesI_Bins] == 2u) {      // the mask of this image never left the bit plane
+        const uint8_t* plane = j.bins + (int64_t)img * (((int64_t)j.H * j.W) >> 3);
+        out[p] = (uint8_t)((plane[p >> 3] >> (p & 7)) & 1u);
+        return;
+    }
     const uint64_t w = j.maskT[((int64_t)img * j.HB + (r >> 6)) * j.W + c];
     out[p] = (uint8_t)((w >> (r & 63)) & 1ull);
 }

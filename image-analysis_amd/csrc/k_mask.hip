@@ -41,6 +41,12 @@ __global__ __launch_bounds__(256) void k_mask_fix(Job j) {
     const uint32_t* list = j.pred_list + (int64_t)img * j.pred_stride;
     const uint8_t* base = j.images + (int64_t)img * j.img_bytes;
     uint64_t* out = j.maskT + (int64_t)img * j.HB * j.W;
+    // Job::pred_fused: the bits stay where the histogram pass wrote them (k_runs_count turns them itself): pixel p is bit p of the plane
+    uint32_t* plane = j.pred_fused ? (uint32_t*)(j.bins + (int64_t)img * (((int64_t)j.H * j.W) >> 3)) : nullptr;
+    auto set_pixel = [&](int64_t p, int r, int c) {
+        if (plane) atomicOr(&plane[p >> 5], 1u << (p & 31));
+        else atomicOr((unsigned long long*)&out[(int64_t)(r >> 6) * j.W + c], 1ull << (r & 63));
+    };
     if (j.dtype == LFA_U16) {                                             // uint16 frames: pixel >= T = x_thr + 1
         const uint32_t T = (uint32_t)j.info[img].x_thr + 1u;
         for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
@@ -49,8 +55,7 @@ __global__ __launch_bounds__(256) void k_mask_fix(Job j) {
             const uint16_t* px = (const uint16_t*)base + p0;
             for (int k = 0; k < 16; ++k) {
                 const uint32_t x = px[k];
-                if (x >= t_lo && x < t_hi && x >= T)
-                    atomicOr((unsigned long long*)&out[(int64_t)(r >> 6) * j.W + c0 + k], 1ull << (r & 63));
+                if (x >= t_lo && x < t_hi && x >= T) set_pixel(p0 + k, r, c0 + k);
             }
         }
         return;
@@ -64,8 +69,7 @@ __global__ __launch_bounds__(256) void k_mask_fix(Job j) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const uint32_t G = gray_G16(w, k);
-            if (G >= t_lo && G < t_hi && G >= G_thr)
-                atomicOr((unsigned long long*)&out[(int64_t)(r >> 6) * j.W + c0 + k], 1ull << (r & 63));
+            if (G >= t_lo && G < t_hi && G >= G_thr) set_pixel(p0 + k, r, c0 + k);
         }
     }
 }
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(256) void k_mask(Job j) {
             G_thr = eg[kEdgesI_MaskThr];
             integer_path = eg[kEdgesI_MaskCrit] == 0;
         }
+        if (PRED && VEC && j.bins && eg[kEdgesI_Bins] == 2u && j.pred_fused) return;      // k_runs_count reads the bit plane itself
         if (PRED && VEC && j.bins && eg[kEdgesI_Bins] == 2u) {
             // Predicted-threshold bit plane (Job::pred_mode): bit = G >= pred_hi, row-major, 16 pixels = one 16-bit word.  The
             // image's threshold lies inside the window, so a set bit is a set pixel and a clear bit a clear pixel except for

@@ -375,6 +375,7 @@ lfa::Job make_job(LfaContext* h, const Workspace& w, const void* images, int dty
     j.thr_list = (C == 1 && dtype == LFA_U16 && j.hist_abs) ? (uint32_t*)h->thr_list.p : nullptr;
     j.pred_list = (uint32_t*)w.bbox.p;
     j.pred_stride = room;
+    j.pred_fused = (j.pred_mode && (W % 64) == 0 && !(h->debug_flags & 65536)) ? 1 : 0;
     j.bins = (j.u16_plane || rgb_plane || j.pred_mode) ? (uint8_t*)w.bins.p : nullptr;
     j.maskT = (uint64_t*)w.maskT.p;
     j.col_cnt = (uint32_t*)w.col_cnt.p;
@@ -513,7 +514,7 @@ int detect_impl(LfaContext* h, const void* images, int dtype, int n, int H, int 
         // no events either: nothing is recorded for, or awaited from, other handles (lfa_stream_wait_passes /
         // lfa_chain_passes do not see static calls), so the call is kernels and memsets on `s` only and can be captured
         j.passes_event = nullptr; j.wait_event = nullptr;
-        j.pred_mode = 0; j.pred_list = nullptr; j.thr_list = nullptr; j.pred_probe_lo = j.pred_probe_hi = 0u;
+        j.pred_mode = 0; j.pred_fused = 0; j.pred_list = nullptr; j.thr_list = nullptr; j.pred_probe_lo = j.pred_probe_hi = 0u;
         j.plane_stats = nullptr; j.bins = nullptr; j.u16_plane = 0; j.hist_abs = 0; j.win_hint = 0; j.grey_mode = 0; j.grey_plane = nullptr;
         j.u16_lds_bins = lfa::kLdsBinsU16; j.u16_pred = 0; j.u16_pa = 0; j.u16_ps = 0;
         if (ws_rois) *ws_rois = (LfaRoi*)w.rois.p;

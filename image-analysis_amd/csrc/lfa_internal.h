@@ -114,6 +114,8 @@ struct Job {
     uint32_t* pred_list;     // [n][pred_stride] indices of the listed groups; lives in the `bbox` buffer like grey_plane
     int64_t pred_stride;
     int32_t pred_cap;        // entries an image may use
+    int32_t pred_fused;      // pred_mode and W % 64 == 0: an image decided from the bit plane keeps its mask THERE -- k_mask skips it, k_mask_fix sets
+                             //         the listed pixels in the plane, k_runs_count turns 64 x 64 bit blocks in the wave (debug flag 65536: off)
     uint32_t pred_lo_raw, pred_hi_raw;   // grey mode: the window before it was widened to whole buckets -- k_grey_hist works in grey levels
                              //         (b_lo = ceil(pred_lo_raw / 10000), b_hi likewise), and a bucket edge must not pull a whole level onto the list
     uint32_t* thr_list;      // [n] uint16, one-pass histogram: T = x_thr + 1 of every frame with few pixels near it, else 0 (k_otsu_int) -> the handle's next window

@@ -204,7 +204,8 @@ int lfa_set_host_pow(LfaHandle h, const LfaHostPow* tables, int n);
  * have held at least half of its frames (T inside it, at most 1/2048 of the pixels inside it); bit13 / bit14 / bit15 act
  * on it as on the colour mode.  Equal-channel images in grey mode (bit10 / the handle's own finding): the window is the
  * last call's range of thresholds as it is, in grey levels -- no margin: a series with one byte threshold has no undecided
- * pixel, any other falls back per image.  Results are identical either way.
+ * pixel, any other falls back per image.  bit16 (65536): the bits of an image they decide are always turned into vertical words
+ * by the mask pass (default for widths that are multiples of 64: the run extraction turns them itself).  Results are identical either way.
  * bit8 (256) / bit9 (512): k_edges_rgb moves every interior gray-space histogram edge it computed one double up / down --
  * what a pow() whose last bit differs would do -- so that the tests can show an image with a pixel exactly on an edge
  * going wrong without lfa_set_host_pow and right with it (tables from lfa_set_host_pow are never touched). */
