@@ -50,25 +50,38 @@ __device__ inline uint64_t drop_short_runs(uint64_t w, uint64_t above, int L) {
 
 // 64 x 64 bit matrix across the wave: lane i comes in with row i (bit k = column k) and leaves with column i (bit k = row k).  Six
 // block swaps between lane pairs (i, i ^ s), s = 32 .. 1: the upper lane of a pair takes its odd s-blocks from the partner's even ones
-// and the lower lane the other way round.  ALL 64 lanes must be here.
+// and the lower lane the other way round.  A lane needs only half of its partner's bits, so what travels is ONE 32-bit word per
+// swap (s = 32: a whole half; below: the wanted blocks of both halves packed side by side), and everything is 32-bit arithmetic.
+// ALL 64 lanes must be here.
 __device__ __forceinline__ uint64_t transpose_bits64(uint64_t w, int lane) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const uint64_t m0 = s == 32 ? 0x00000000ffffffffull : s == 16 ? 0x0000ffff0000ffffull : s == 8 ? 0x00ff00ff00ff00ffull
-                          : s == 4 ? 0x0f0f0f0f0f0f0f0full : s == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
-        const uint64_t pw = __shfl_xor(w, s);
-        w = (lane & s) ? ((w & ~m0) | ((pw & ~m0) >> s)) : ((w & m0) | ((pw & m0) << s));
+    uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+    {
+        const bool up = lane & 32;
+        const uint32_t got = __shfl_xor(up ? lo : hi, 32);
+        if (up) lo = got; else hi = got;
     }
-    return w;
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+        const uint32_t m = s == 16 ? 0x0000ffffu : s == 8 ? 0x00ff00ffu : s == 4 ? 0x0f0f0f0fu : s == 2 ? 0x33333333u : 0x55555555u;
+        const bool up = lane & s;
+        // lower lane sends its odd blocks (lo's moved down beside hi's), upper lane its even blocks (hi's moved up beside lo's)
+        const uint32_t send = up ? ((lo & m) | ((hi & m) << s)) : (((lo & ~m) >> s) | (hi & ~m));
+        const uint32_t x = __shfl_xor(send, s);
+        if (up) { lo = (lo & ~m) | (x & m);         hi = (hi & ~m) | ((x & ~m) >> s); }
+        else    { lo = (lo & m) | ((x & m) << s);   hi = (hi & m) | (x & ~m); }
+    }
+    return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-// Walk one column top to bottom -- word(rb) = its 64-row word of row block rb -- and call emit(start, end_inclusive) for every
-// surviving run.
-template <class Word, class Emit>
-__device__ inline void column_runs(const Word& word, int HB, int H, int L, const Emit& emit) {
+// Walk one column top to bottom, one 64-row word at a time (step(w, rb), rb ascending, then finish()), and call
+// emit(start, end_inclusive) for every surviving run.
+template <class Emit>
+struct ColumnWalk {
+    const Emit& emit;
+    const int H, L;
     int start = -1;
-    for (int rb = 0; rb < HB; ++rb) {
-        uint64_t w = word(rb);
+    __device__ ColumnWalk(const Emit& e, int H_, int L_) : emit(e), H(H_), L(L_) {}
+    __device__ __forceinline__ void step(uint64_t w, int rb) {
         uint64_t t = w ^ ((w << 1) | (start >= 0 ? 1ull : 0ull));       // bit k set: mask changes between row k-1 and k
         if (__popcll((unsigned long long)t) > 8) {                       // a noisy word: most of its runs are too short to survive
             const int rem = H - rb * 64;
@@ -86,15 +99,27 @@ __device__ inline void column_runs(const Word& word, int HB, int H, int L, const
             }
         }
     }
-    if (start >= 0 && run_survives(start, H - 1, H, L)) emit(start, H - 1);
+    __device__ __forceinline__ void finish() { if (start >= 0 && run_survives(start, H - 1, H, L)) emit(start, H - 1); }
+};
+template <class Word, class Emit>   // word(rb) = the column's 64-row word of row block rb
+__device__ inline void column_runs(const Word& word, int HB, int H, int L, const Emit& emit) {
+    ColumnWalk<Emit> walk(emit, H, L);
+    for (int rb = 0; rb < HB; ++rb) walk.step(word(rb), rb);
+    walk.finish();
 }
 
 // one thread per column: count the surviving runs and park them in the column's own slots of run_tmp (run_cap is
 // runs_per_col * W, and runs_per_col bounds what a column can hold), so that k_runs_fill compacts the run list
 // without reading the mask a second time
-__global__ __launch_bounds__(256) void k_runs_count(Job j) {
-    const int img = blockIdx.y;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// Blocks are dealt to the eight XCDs in turn (block b runs on XCD b % 8) and every XCD has an L2 of its own, so the numbering is
+// folded: the blocks of one image -- which share every row's cache lines of the bit plane, 32 bytes of each per block -- are
+// neighbours on ONE XCD instead of one on each (measured: 4x the plane's bytes from HBM before).
+__global__ __launch_bounds__(256) void k_runs_count(Job j, int gx) {
+    const int total = gridDim.x;
+    const int b = blockIdx.x;
+    const int v = (total & 7) ? b : (b & 7) * (total >> 3) + (b >> 3);
+    const int img = v / gx;
+    const int c = (v - img * gx) * blockDim.x + threadIdx.x;
     if (c >= j.W) return;
     int n = 0;
     uint32_t* tmp = j.run_tmp + (int64_t)img * j.run_cap + (int64_t)c * j.runs_per_col;
@@ -112,12 +137,28 @@ __global__ __launch_bounds__(256) void k_runs_count(Job j) {
         const uint64_t* plane = (const uint64_t*)(j.bins + (int64_t)img * (((int64_t)H * j.W) >> 3));
         const int64_t wpr = j.W >> 6;                               // 64-bit words per row
         auto rows = [&](int rb) -> uint64_t { const int r = rb * 64 + lane; return (rb < j.HB && r < H) ? plane[(int64_t)r * wpr + (c0 >> 6)] : 0ull; };
-        uint64_t n1 = rows(0);
-        column_runs([&](int rb) -> uint64_t {
-                        const uint64_t cur = n1; n1 = rows(rb + 1);
-                        // (leaving the all-clear blocks -- most of an image -- unturned was measured slower: 0.50 against 0.34 ms per 1024 images)
-                        return transpose_bits64(cur, lane);
-                    }, j.HB, H, j.line_length, emit);
+        // Row blocks travel kAhead at a time, one batch ahead of the one being turned: a wave's loads depend on nothing but the
+        // block number, and one at a time their latencies -- 24 of them in a 1536-row image, with the image passes of the next
+        // chunk keeping HBM busy -- were the kernel's whole duration.
+        constexpr int kAhead = 8;
+        uint64_t cur[kAhead], nxt[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) nxt[k] = rows(k);
+        ColumnWalk<decltype(emit)> walk(emit, H, j.line_length);
+        for (int base = 0; base < j.HB; base += kAhead) {
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) { cur[k] = nxt[k]; nxt[k] = rows(base + kAhead + k); }
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k)
+                if (base + k < j.HB) {                                                          // uniform across the wave
+                    // a 64 x 64 block that is all background or all foreground (most of a strip image) is its own transpose
+                    // (and nothing happens in it when no column has a run open / every column has)
+                    const bool zeros = __ballot(cur[k] != 0ull) == 0ull, ones = __ballot(cur[k] != ~0ull) == 0ull;
+                    if (!(zeros || ones)) walk.step(transpose_bits64(cur[k], lane), base + k);
+                    else if (__ballot(zeros ? walk.start >= 0 : walk.start < 0) != 0ull) walk.step(cur[k], base + k);
+                }
+        }
+        walk.finish();
     } else {
         const uint64_t* colw = j.maskT + (int64_t)img * j.HB * j.W + c;
         const int W = j.W;
@@ -392,8 +433,8 @@ __global__ __launch_bounds__(1024) void k_components(Job j) {
 }
 
 hipError_t launch_label(const Job& j, hipStream_t s) {
-    const dim3 gcol((j.W + 255) / 256, j.n);
-    LFA_LAUNCH("k_runs_count", k_runs_count, gcol, dim3(256), 0, s, j);
+    const int gx = (j.W + 255) / 256;
+    LFA_LAUNCH("k_runs_count", k_runs_count, dim3(gx * j.n), dim3(256), 0, s, j, gx);
     LFA_LAUNCH("k_components", k_components, dim3(j.n), dim3(1024), 0, s, j);
     return hipGetLastError();
 }
