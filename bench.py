@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=3, help="lanes (one LfaHandle + one HIP stream each) the chunks take in turn")
     ap.add_argument("--stagger", type=int, default=2, help="0: lanes run free; 1: a chunk's kernels start when the previous chunk's histogram pass is done (lfa_stream_wait_passes); 2: only its image passes wait (lfa_chain_passes)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="in the timed region every N-th launch of the dominant kernel (per lane) is bracketed by HIP events; "
+                         "1 = every launch (the records between the kernels then cost about 2 %% of the step)")
     ap.add_argument("--free-running", action="store_true", help="after the timed region, time the same steps again with no ordering between the lanes (reported as `free_running`); off by default so that a profile of the default command holds one schedule only")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary configurations (the `configs` object)")
     ap.add_argument("--config-steps", type=int, default=10, help="timed steps of each secondary configuration")
@@ -255,7 +258,7 @@ def main():
         warm_times = merge_times([e.timing_read() for e in engs])
         dominant = max(warm_times, key=lambda k: warm_times[k][0])
         for e in engs:
-            e.timing(dominant)
+            e.timing(dominant if args.time_every <= 1 else "%s/%d" % (dominant, args.time_every))
 
     # ---- timed region ----
     barrier()
@@ -362,7 +365,9 @@ def main():
                     traffic_source = tj.get("_source", "profiles/traffic.json")
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": launches, "algorithmic_bytes_per_launch": alg_bytes,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+                    "launches_in_timed_region": args.steps * ((B + CH - 1) // CH), "timed_every": max(1, args.time_every),
+                    "algorithmic_bytes_per_launch": alg_bytes,
                     "frac_with_plane_store": round((alg_bytes + CH * own_store) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "plane_store_bytes_per_launch": CH * own_store,
                     "note": (f"timed region: {NS} lanes, the image passes of consecutive chunks chained (lfa_chain_passes), so a launch of "
@@ -370,6 +375,9 @@ def main():
                              if NS > 1 and args.stagger == 2 else
                              f"timed region: {NS} lanes running free: a launch shares the CUs with the other lanes' passes, so `frac` says "
                              "how much else ran beside the kernel, not how well it uses the memory system; ") +
+                            "every `timed_every`-th launch of it on each lane is bracketed by HIP events (`launches` of "
+                            "`launches_in_timed_region`; --time-every 1 brackets all of them, at about 2 % of the step for the "
+                            "records between the kernels); "
                             "`isolated` is the same kernel in one extra untimed step on a single stream; `traffic` is "
                             "not measured in this run: it is the PMC figure (2*FETCH_SIZE + WRITE_SIZE, KiB units) of the "
                             "rocprofv3 passes named in `traffic_source`"}

@@ -1178,10 +1178,10 @@ __global__ __launch_bounds__(256) void k_otsu_rgb(Job j) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-static int blocks_per_image(const Job& j, int px_per_block) {
+static int blocks_per_image(const Job& j, int px_per_block, int launch_blocks = 4096) {
     const int64_t npix = (int64_t)j.H * j.W;
     int64_t need = (npix + px_per_block - 1) / px_per_block;
-    int64_t want = (4096 + j.n - 1) / j.n;          // keep the whole launch around 4096 blocks
+    int64_t want = (launch_blocks + j.n - 1) / j.n;          // keep the whole launch around 4096 blocks
     if (want < 1) want = 1;
     if (need > want) need = want;
     if (need < 1) need = 1;
@@ -1197,19 +1197,6 @@ static int blocks_per_image(const Job& j, int px_per_block) {
         case 4: LFA_LAUNCH(#KERNEL, KERNEL<4>, GRID, BLOCK, 0, STREAM, JOB); break;              \
         default: LFA_LAUNCH(#KERNEL, KERNEL<5>, GRID, BLOCK, 0, STREAM, JOB); break;             \
     }
-
-// blocks of k_hist_rgb the chip holds at once.  Queried once per process -- by lfa_create, so that no detect / analyze
-// call makes a runtime query (a call may be under stream capture: lfa_analyze_batch_static).
-int hist_rgb_capacity() {
-    static const int capacity = [] {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_hist_rgb<0>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1024;
-        return per_cu * prop.multiProcessorCount;
-    }();
-    return capacity;
-}
 
 hipError_t launch_threshold(const Job& j, hipStream_t s) {
     LFA_LAUNCH("k_init_info", k_init_info, dim3(j.H >= 4096 ? 8 : 2, j.n), dim3(256), 0, s, j);
@@ -1227,16 +1214,23 @@ hipError_t launch_threshold(const Job& j, hipStream_t s) {
         static const int mm_bpi = [] { const char* e = getenv("LFA_MM_BPI"); return e ? atoi(e) : 0; }();
         const dim3 grid(mm_bpi > 0 ? mm_bpi : blocks_per_image(j, 256 * 64), j.n);
         if (j.grey_mode) LFA_LAUNCH("k_grey_hist", k_grey_hist, grid, dim3(256), 0, s, j);
-        LFA_DISPATCH_V(k_minmax_rgb, grid, dim3(256), s, j);
+        // 6144 blocks per launch for the min/max pass and (below) for the histogram pass, not 4096 and 3840 (two rounds of what the chip
+        // holds of the one, three of the other): measured on the headline step over both grids (tools/r3_bpi_matrix.sh), 3.98 -> 3.84 ms.  The kernel trace says why it is the STEP
+        // that moves: the tail kernels of the chunks before get onto a CU only where a pass's block retires without a successor
+        // waiting, so they run in the seams between the rounds -- more, shorter rounds let them through earlier and in smaller pieces
+        // (one round each, the other extreme: 4.05-4.23 ms).
+        const dim3 gridmm(mm_bpi > 0 ? mm_bpi : blocks_per_image(j, 256 * 64, 6144), j.n);
+        LFA_DISPATCH_V(k_minmax_rgb, gridmm, dim3(256), s, j);
         LFA_LAUNCH("k_edges_rgb", k_edges_rgb, dim3(j.n), dim3(256), 0, s, j);
         {
-            // the histogram blocks live for the whole launch (grid-stride), so the grid is sized to whole rounds of
-            // what the chip holds at once: 4096 blocks on a capacity of 1280 would run 3.2 rounds, i.e. pay for 4
-            const int capacity = hist_rgb_capacity();
-            int per_image = (3 * capacity + j.n / 2) / j.n;
+            // the histogram blocks live for the whole launch (grid-stride) and the chip holds 1280 of them at once; the grid
+            // was three whole rounds of that (15 per image at 256 images) until the sweep above: 6144 blocks, as for the min/max pass
+            int per_image = (6144 + j.n / 2) / j.n;
             const int need = (int)(((int64_t)j.H * j.W + 256 * 64 - 1) / (256 * 64));
             if (per_image > need) per_image = need;
             if (per_image < 1) per_image = 1;
+            static const int hist_bpi = [] { const char* e = getenv("LFA_HIST_BPI"); return e ? atoi(e) : 0; }();
+            if (hist_bpi > 0) per_image = hist_bpi;
             const dim3 gridh(per_image, j.n);
             LFA_DISPATCH_V(k_hist_rgb, gridh, dim3(256), s, j);
         }

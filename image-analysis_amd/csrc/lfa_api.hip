@@ -57,6 +57,7 @@ struct Buf {
 struct EventTimer : lfa::KernelTimer {
     struct Rec { std::string name; hipEvent_t a, b; };
     std::string filter;                // "*" = every kernel, else exact kernel name
+    int every = 1, seen = 0;           // "name/N": every N-th launch of that kernel only (two event records per launch are not free)
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
     bool open = false;
@@ -69,6 +70,7 @@ struct EventTimer : lfa::KernelTimer {
     void begin(const char* name, hipStream_t s) override {
         open = false;
         if (filter != "*" && filter != name) return;
+        if (every > 1 && (seen++ % every) != 0) return;
         Rec r{name, get(), get()};
         if (!r.a || !r.b) return;
         if (hipEventRecord(r.a, s) != hipSuccess) return;
@@ -589,7 +591,6 @@ int lfa_create(int device, int max_h, int max_w, int max_c, int max_batch, LfaHa
         lfa_destroy(h);
         return fail(LFA_ERR_HIP, "uploading gamma tables failed");
     }
-    (void)lfa::hist_rgb_capacity();                                               // the one runtime query of the launchers, made here
     if ((rc = static_scratch_lookup(device))) { lfa_destroy(h); return rc; }      // set-up of lfa_analyze_batch_static, once per device
     // the whole workspace for calls within the handle's limits at the defaults (line_length >= 10, max_strips <= 64), class
     // plane and big-image Otsu buffers included; lfa_reserve widens those two limits
@@ -965,6 +966,14 @@ int lfa_timing_enable(LfaHandle h, const char* kernel_filter) {
     if (!h->timer) h->timer = new (std::nothrow) EventTimer();
     if (!h->timer) return fail(LFA_ERR_NOMEM, "out of host memory");
     h->timer->filter = kernel_filter;
+    h->timer->every = 1; h->timer->seen = 0;
+    const size_t slash = h->timer->filter.find('/');
+    if (slash != std::string::npos) {
+        const int n = std::atoi(h->timer->filter.c_str() + slash + 1);
+        if (n < 1) return fail(LFA_ERR_ARG, "lfa_timing_enable: \"%s\": the launch stride after '/' must be >= 1", kernel_filter);
+        h->timer->every = n;
+        h->timer->filter.resize(slash);
+    }
     return LFA_OK;
 }
 

@@ -150,7 +150,6 @@ extern thread_local KernelTimer* g_timer;
     } while (0)
 
 // --- launchers (each enqueues on `s` and returns the launch status) -----------------------------------------------
-int hist_rgb_capacity();                                                  // resident k_hist_rgb blocks per chip (queried once, lfa_create)
 hipError_t launch_threshold(const Job& j, hipStream_t s);                 // min/max, histogram, Otsu -> info
 hipError_t launch_mask(const Job& j, hipStream_t s);                      // thresholded image -> maskT
 hipError_t launch_label(const Job& j, hipStream_t s);                     // opening + runs + union-find + ranks

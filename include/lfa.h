@@ -386,7 +386,9 @@ int lfa_debug_fetch(LfaHandle h, int image_index, int what, void* out, int64_t o
 /* ---- per-kernel timing for bench.py (no counterpart in the reference) ---------------------------------------------- */
 
 /* kernel_filter: "*" brackets every kernel launch made through this handle with a pair of hipEvents on the launch
- * stream, "<kernel name>" only that kernel, NULL or "" switches timing off.  lfa_timing_read waits for the device,
+ * stream, "<kernel name>" only that kernel, "<kernel name>/N" only every N-th launch of it (the event records sit between
+ * the kernels of a stream: bracketing every launch of the headline's dominant kernel cost 2 % of the step), NULL or ""
+ * switches timing off.  lfa_timing_read waits for the device,
  * returns the summed milliseconds and launch counts per kernel name since the last read (names: max_entries slots of
  * 32 bytes, HOST memory) and forgets them. */
 int lfa_timing_enable(LfaHandle h, const char* kernel_filter);

@@ -623,7 +623,7 @@ def test_random_small_images_against_oracle(capi, eng, seed):
         mm_r, mm_c = int(rng.integers(0, max(1, H))), int(rng.integers(0, max(1, W // 2 + 1)))
         # colour: default choice of the class plane, or forced; uint16: default, or one-pass histogram with the plane forced
         # (its classes centred on whatever threshold the shared handle met last), or the two-pass histogram
-        eng.set_debug_flags(int(rng.choice([0, 4, 0, 1024, 1024 | 1, 1024 | 4096, 8192, 16384, 32768, 32768 | 1])) if kind == 2 else (int(rng.choice([0, 16 | 4, 8, 16 | 32768, 16 | 8192, 16 | 16384])) if kind == 1 else 0))
+        eng.set_debug_flags(int(rng.choice([0, 4, 0, 1024, 1024 | 1, 1024 | 4096, 8192, 16384, 32768, 32768 | 1, 65536, 32768 | 65536])) if kind == 2 else (int(rng.choice([0, 16 | 4, 8, 16 | 32768, 16 | 8192, 16 | 16384])) if kind == 1 else 0))
         try:
             check_detect(capi, eng, arr, mm_r, mm_c, L)
         finally:
@@ -911,6 +911,38 @@ def test_predicted_threshold_mode_matches_the_oracle(capi):
         e.set_debug_flags(0)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("shape", [(70, 64), (129, 128), (300, 576), (64, 192), (1, 64)])
+def test_predicted_threshold_bits_turned_in_the_run_extraction_or_by_k_mask(capi, shape):
+    """Widths that are multiples of 64: an image decided from the predicted-threshold bit plane never gets a transposed mask --
+    k_runs_count loads 64 x 64 bit blocks of the plane and turns them in the wave (blocks that are all clear or all set are not
+    turned), k_mask_fix sets the listed pixels in the plane.  Debug flag 65536 sends the same call through k_mask instead.  Both
+    ways equal the oracle in every intermediate: heights off the 64-row grid, noisy masks (no flat block, short runs that the
+    opening drops), flat images with a few strips, and every pixel through the list (flag 32768)."""
+    from image_analysis_amd.synth import synth_rgb
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    strips = np.stack([synth_rgb(max(H, 16), W, 3, 500 + k)[:H] for k in range(3)])
+    noisy = strips.copy()
+    speck = rng.random((3, H, W)) < 0.3
+    noisy[speck] = 255 - noisy[speck]                                  # salt and pepper on both sides of any threshold
+    mm_r, mm_c = gui_params(strips[0])
+    for batch in (strips, noisy):
+        for flags in (0, 65536, 32768, 32768 | 65536):
+            e = capi.Engine(device=0, max_h=H, max_w=W, max_batch=3)
+            try:
+                e.set_debug_flags(flags & 65536)
+                e.detect(batch, mm_r, mm_c, 10)                        # the call the window comes from
+                e.set_debug_flags(flags)
+                for L in (10, 3):
+                    res = e.detect(batch, mm_r, mm_c, L)
+                    took = [e.debug_pred_path(i) for i in range(3)]
+                    for i in range(3):
+                        check_detect(capi, e, batch[i], mm_r, mm_c, L, batch_index=i, res=res)
+                    assert all(took) or (flags & 32768) or H == 1, (flags, took)   # (forced window: the list may overflow -> compare on the image)
+            finally:
+                e.close()
 
 
 def test_predicted_threshold_mode_in_analyze_batch_and_across_shapes(capi):
