@@ -52,24 +52,34 @@ __device__ inline uint64_t drop_short_runs(uint64_t w, uint64_t above, int L) {
 // block swaps between lane pairs (i, i ^ s), s = 32 .. 1: the upper lane of a pair takes its odd s-blocks from the partner's even ones
 // and the lower lane the other way round.  A lane needs only half of its partner's bits, so what travels is ONE 32-bit word per
 // swap (s = 32: a whole half; below: the wanted blocks of both halves packed side by side), and everything is 32-bit arithmetic.
-// ALL 64 lanes must be here.
+// The words travel by v_permlane32_swap (s = 32), ds_swizzle (16, 8, 4) and DPP quad permutes (2, 1).  ALL 64 lanes must be here.
+template <int S>
+__device__ __forceinline__ void transpose_swap32(uint32_t& lo, uint32_t& hi, int lane) {
+    constexpr uint32_t m = S == 16 ? 0x0000ffffu : S == 8 ? 0x00ff00ffu : S == 4 ? 0x0f0f0f0fu : S == 2 ? 0x33333333u : 0x55555555u;
+    // The upper lane of a pair (bit S of the lane number set) keeps its odd S-blocks and sends its even ones, the lower lane the other
+    // way round.  No branch and no select: with b = S in the upper lane, 0 in the lower, and a = S - b, the word sent is lo's wanted
+    // blocks moved down beside hi's moved up, and what arrives is shifted back into the blocks not kept.  (These depend on the lane
+    // only: the compiler keeps them in registers across the row blocks.)
+    const uint32_t b = (uint32_t)lane & (uint32_t)S, a = (uint32_t)S - b;
+    const uint32_t keep = b ? ~m : m;
+    const uint32_t send = (m & (lo >> a)) | (~m & (hi << b));
+    uint32_t x;
+    if (S >= 4) x = (uint32_t)__builtin_amdgcn_ds_swizzle((int)send, (S << 10) | 0x1f);                       // lane ^ S inside 32 lanes, no address register
+    else        x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, S == 2 ? 0x4e : 0xb1, 0xf, 0xf, false);   // quad_perm [2,3,0,1] / [1,0,3,2]
+    lo = (keep & lo) | (~keep & (x << a));
+    hi = (keep & hi) | (~keep & (x >> b));
+}
 __device__ __forceinline__ uint64_t transpose_bits64(uint64_t w, int lane) {
-    uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-    {
-        const bool up = lane & 32;
-        const uint32_t got = __shfl_xor(up ? lo : hi, 32);
-        if (up) lo = got; else hi = got;
-    }
-#pragma unroll
-    for (int s = 16; s >= 1; s >>= 1) {
-        const uint32_t m = s == 16 ? 0x0000ffffu : s == 8 ? 0x00ff00ffu : s == 4 ? 0x0f0f0f0fu : s == 2 ? 0x33333333u : 0x55555555u;
-        const bool up = lane & s;
-        // lower lane sends its odd blocks (lo's moved down beside hi's), upper lane its even blocks (hi's moved up beside lo's)
-        const uint32_t send = up ? ((lo & m) | ((hi & m) << s)) : (((lo & ~m) >> s) | (hi & ~m));
-        const uint32_t x = __shfl_xor(send, s);
-        if (up) { lo = (lo & ~m) | (x & m);         hi = (hi & ~m) | ((x & ~m) >> s); }
-        else    { lo = (lo & m) | ((x & m) << s);   hi = (hi & m) | (x & ~m); }
-    }
+    // s = 32: the upper half-wave's low words change places with the lower half-wave's high words -- one instruction on gfx950
+    const auto sw = __builtin_amdgcn_permlane32_swap((uint32_t)w, (uint32_t)(w >> 32), false, false);
+    uint32_t lo = sw[0], hi = sw[1];
+    // (one instantiation per swap: left as a loop over s the compiler kept it a loop -- around a switch for the mask -- in the eight-fold
+    //  unrolled body of k_runs_count)
+    transpose_swap32<16>(lo, hi, lane);
+    transpose_swap32<8>(lo, hi, lane);
+    transpose_swap32<4>(lo, hi, lane);
+    transpose_swap32<2>(lo, hi, lane);
+    transpose_swap32<1>(lo, hi, lane);
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 

@@ -613,9 +613,19 @@ hipError_t launch_profiles(const Job& j, const LfaRoi* rois, int n_rois, const i
         if (luts)
             LFA_LAUNCH("k_profile_lut", (k_profile<64, true>), grid, block, acc_bytes + (size_t)waves * 256, s, j, rois, n_rois, counts,
                        slots, rs_off, inverse, rng, profiles, stride, peaks, lstride, luts, roi_lut, n_luts, nullptr);
-        else
-            LFA_LAUNCH("k_profile", (k_profile<64, false>), grid, block, acc_bytes, s, j, rois, n_rois, counts, slots, rs_off,
+        else {
+            // Chained lanes (lfa_chain_passes): this kernel and k_peaks behind it are kept out of the next chunk's histogram pass -- which
+            // is bound by its VALU and LDS work and stretches by a tenth with them beside it -- by asking for 60 KiB of LDS: that does
+            // not fit beside three k_hist_rgb blocks (or two of k_hist_u16) nor into the room one retiring block leaves, so the
+            // kernel runs in the seam after the pass, where the tail's other half runs anyway.  Measured with the faster
+            // k_runs_count (its successor k_components then starts BEFORE the histogram pass and the rest of the tail followed it
+            // into the pass): headline 3.98 -> 3.83 ms, configs[2] 3.40 -> 3.35 ms per 1024 frames.  Not behind the equal-channel pass
+            // (k_grey_hist reads at the HBM ceiling and has VALU time to spare: gated 2.97 ms, not gated 2.90) and not for lanes
+            // that run free (configs[3]).
+            const size_t gate = (j.wait_event && !j.grey_mode && counts) ? (size_t)60 * 1024 : (size_t)0;
+            LFA_LAUNCH("k_profile", (k_profile<64, false>), grid, block, acc_bytes > gate ? acc_bytes : gate, s, j, rois, n_rois, counts, slots, rs_off,
                        inverse, rng, profiles, stride, peaks, lstride, luts, roi_lut, n_luts, band_rows ? roi_idx : nullptr);
+        }
     }
     // peaks: the sequential search, 16 lanes per profile
     launch_peaks_k(profiles, nullptr, n_rois, stride, max_len, inverse, 25, 1, rng, peaks, j, rois, counts, slots,
