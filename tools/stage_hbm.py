@@ -31,6 +31,7 @@ for cfg in ("bench", "cfg2", "photo", "cfg4", "gauss", "lines"):
 with open(f"{P}/r03_stage_hbm.csv", "w") as fo:
     fo.write("# HBM bytes per launch from the PMC passes (2*FETCH_SIZE + WRITE_SIZE, KiB) / launch duration from rocprofv3 --stats; GB/s against 8000 GB/s\n")
     fo.write("# 2*FETCH_SIZE = bytes of the 128-byte lines fetched: calibrated for streaming reads (MI355X_MICROARCH.md) and for scattered 16..64-byte pieces (profiles/r03_scatter_probe.csv), i.e. for every row\n")
+    fo.write("# durations are those of the PIPELINED run: a tail kernel's launch lasts from its dispatch to its last block, and its blocks wait for CUs while another chunk's image pass holds them (the empty k_mask of a settled handle: 290 us; k_profile behind its LDS gate: the rest of a histogram pass) -- for the tail kernels the *_best columns and the one-stream times in the bench line's kernel_ms_per_step are the kernel, the averages are the schedule (DESIGN.md, 'Where the tail kernels run')\n")
     fo.write("config,kernel,launches,hbm_bytes_per_launch,average_ns,GBps_average,frac_of_peak_average,min_ns,GBps_best,frac_of_peak_best\n")
     for r in rows:
         fo.write(f"{r[0]},{r[1]},{r[2]},{r[3]},{r[4]:.0f},{r[5]:.1f},{r[6]:.3f},{r[7]:.0f},{r[8]:.1f},{r[9]:.3f}\n")
