@@ -408,6 +408,8 @@ int lfa_stream_wait_passes(LfaHandle producer, void* stream);
  * nothing but the passes themselves is held back.  With handles h0 .. h(k-1) taking consecutive batches in turn and
  * h(i) chained after h(i-1) (h0 after h(k-1)), at most one batch is in its min/max or histogram pass at any time: those
  * passes run at their stand-alone speed, one behind the other, and the tails of the batches before run beside them.
+ * (On a chained handle the profile kernel of lfa_analyze_batch asks for 60 KiB of LDS it does not use, so that it and the
+ * peak search behind it run after the histogram pass of the next batch instead of beside it; results do not depend on it.)
  * producer NULL ends the rule.  Both handles must be on the same device; end the rule before destroying `producer`. */
 int lfa_chain_passes(LfaHandle consumer, LfaHandle producer);
 
