@@ -673,7 +673,12 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     uint32_t* shl = sh + (threadIdx.x & (kHC - 1));
     auto hadd = [&](uint32_t k) { atomicAdd(&shl[k * kHC], 1u); };
     const double* te = j.edges_g + (int64_t)img * kEdges;
+    __shared__ uint32_t sg[kEdges + 3];
+    const uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
+    // (both edge lists are fetched before the one barrier: a block's start costs one trip to memory, not two)
     for (int k = threadIdx.x; k < kEdges; k += 256) st[k] = te[k];
+    for (int k = threadIdx.x; k < kEdges + 3; k += 256) sg[k] = (k < 256) ? eg[k] : kGInf;   // sentinel above bin 255
+    const bool integer_path = eg[kEdgesI_Crit] == 0;
     __syncthreads();
     const uint8_t* base = j.images + (int64_t)img * j.img_bytes;
     const int64_t npix = (int64_t)j.H * j.W;
@@ -684,9 +689,6 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     // compares against the edges
     const float vminf = (float)j.info[img].vmin;
     const float scalef = 256.0f / ((float)j.info[img].vmax - vminf);
-    const uint32_t* eg = j.edges_i + (int64_t)img * kEdgesI;
-    const bool integer_path = eg[kEdgesI_Crit] == 0;
-    __shared__ uint32_t sg[kEdges + 3];
     // integer path: one table entry per bucket of 1024 G values (G <= 2 550 000 < 2^22):
     //   .x      the next edge above the bucket's first G (clamped to 2^22-1 = never reached)
     //   .y      bits 0-7 the bin of the bucket's first G; bit 30: a second edge lies inside the bucket as well (only for
@@ -698,10 +700,13 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
     __shared__ uint2 tab[2496];
     __shared__ lfa_u32x4 turn[4][192];
     if (integer_path) {
-        for (int k = threadIdx.x; k < kEdges + 3; k += 256) sg[k] = (k < 256) ? eg[k] : kGInf;   // sentinel above bin 255
-        __syncthreads();
-        for (int b = threadIdx.x; b < 2496; b += 256) {
-            const uint32_t G0 = (uint32_t)b << 10;
+        // A thread takes ten consecutive buckets: one binary search for the first, then the bin only moves forward (a block builds
+        // this table before its first pixel and the launch runs eight rounds of blocks per CU: ten searches of eight dependent
+        // LDS reads each per thread were 3 us per block, a twentieth of the pass).
+        constexpr int kPer = (2496 + 255) / 256;
+        {
+            const int b0 = threadIdx.x * kPer;
+            uint32_t G0 = (uint32_t)b0 << 10;
             int lo = 0, hi = 255;                           // largest k with sg[k] <= G0  (sg[0] = 0)
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
@@ -710,10 +715,13 @@ __global__ __launch_bounds__(256) void k_hist_rgb(Job j) {
                 lo = ge ? mid : lo;
                 hi = ge ? hi : mid - 1;
             }
-            const uint32_t e1 = sg[lo + 1] < 0x3fffffu ? sg[lo + 1] : 0x3fffffu;
-            const uint32_t two = (sg[lo + 2] <= G0 + 1023u) ? 0x40000000u : 0u;
-            const uint32_t win = !j.pred_mode ? 0u : (G0 >= j.pred_hi ? 0x80000000u : (G0 >= j.pred_lo ? 0x20000000u : 0u));
-            tab[b] = make_uint2(e1, (uint32_t)lo | two | win);
+            for (int b = b0; b < b0 + kPer && b < 2496; ++b, G0 += 1024u) {
+                while (lo < 255 && sg[lo + 1] <= G0) ++lo;
+                const uint32_t e1 = sg[lo + 1] < 0x3fffffu ? sg[lo + 1] : 0x3fffffu;
+                const uint32_t two = (sg[lo + 2] <= G0 + 1023u) ? 0x40000000u : 0u;
+                const uint32_t win = !j.pred_mode ? 0u : (G0 >= j.pred_hi ? 0x80000000u : (G0 >= j.pred_lo ? 0x20000000u : 0u));
+                tab[b] = make_uint2(e1, (uint32_t)lo | two | win);
+            }
         }
         __syncthreads();
     }
