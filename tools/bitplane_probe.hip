@@ -4,6 +4,7 @@
 // nontemporal 16-byte loads per lane (the shape of k_minmax_rgb / k_hist_rgb / k_grey_hist) and writes 16 bits per lane and round:
 //   0 no store   1 2-byte store per lane (what the passes do)   2 the same, nontemporal   3 8 lanes store 16 bytes (gathered in LDS)
 //   4 32 lanes store 4 bytes (pairs joined by DPP)   5 as 3, nontemporal   6 2-byte stores into 512 bytes rewritten over and over
+//   9 no store, but the round goes through the 3 KiB LDS turn of the real passes (coalesced pieces in, 48 contiguous bytes per lane out)
 //   7 the block keeps its bits in LDS and writes them at its end, 16 bytes per lane (one burst of <= 24 KiB per block)   8 the same, nontemporal
 // Build: hipcc --offload-arch=gfx950 -O3 tools/bitplane_probe.hip -o tools/bitplane_probe
 #include <hip/hip_runtime.h>
@@ -17,6 +18,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_pass(const u32x4* img, uint8_t* plane, int rounds, uint32_t* sink) {
     __shared__ uint16_t buf[4][64];
     __shared__ u32x4 keep[(MODE == 7 || MODE == 8) ? 1536 : 1];      // 24 KiB: 192 rounds
+    __shared__ u32x4 turn[MODE == 9 ? 4 : 1][MODE == 9 ? 192 : 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int per = (rounds + gridDim.x - 1) / gridDim.x;
     const int r_end = min(rounds, (int)(blockIdx.x + 1) * per);
@@ -29,8 +31,10 @@ __global__ __launch_bounds__(256) void k_pass(const u32x4* img, uint8_t* plane, 
     };
     if (r < r_end) request(r);
     for (; r < r_end; r += 4) {
-        const u32x4 a = n0, b = n1, c = n2;
+        u32x4 a = n0, b = n1, c = n2;
+        if (MODE == 9) { turn[wv][lane] = a; turn[wv][64 + lane] = b; turn[wv][128 + lane] = c; }
         if (r + 4 < r_end) request(r + 4);
+        if (MODE == 9) { a = turn[wv][3 * lane]; b = turn[wv][3 * lane + 1]; c = turn[wv][3 * lane + 2]; }
         const uint32_t x = a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w;
         const uint32_t bits = (x ^ (x >> 16)) & 0xffffu;
         acc += bits;
@@ -83,10 +87,11 @@ int main() {
     CK(hipMemset(img, 3, img_bytes)); CK(hipMemset(plane, 0, plane_bytes));
     printf("mode,blocks,ms,image_GBps\n");
     for (int blocks : {4096, 6144}) {
-        const float t[9] = {run<0>(img, plane, rounds, sink, blocks), run<1>(img, plane, rounds, sink, blocks), run<2>(img, plane, rounds, sink, blocks),
+        const float t[10] = {run<0>(img, plane, rounds, sink, blocks), run<1>(img, plane, rounds, sink, blocks), run<2>(img, plane, rounds, sink, blocks),
                             run<3>(img, plane, rounds, sink, blocks), run<4>(img, plane, rounds, sink, blocks), run<5>(img, plane, rounds, sink, blocks),
-                            run<6>(img, plane, rounds, sink, blocks), run<7>(img, plane, rounds, sink, blocks), run<8>(img, plane, rounds, sink, blocks)};
-        for (int m = 0; m < 9; ++m) printf("%d,%d,%.4f,%.0f\n", m, blocks, t[m], img_bytes / (t[m] * 1e-3) / 1e9);
+                            run<6>(img, plane, rounds, sink, blocks), run<7>(img, plane, rounds, sink, blocks), run<8>(img, plane, rounds, sink, blocks),
+                            run<9>(img, plane, rounds, sink, blocks)};
+        for (int m = 0; m < 10; ++m) printf("%d,%d,%.4f,%.0f\n", m, blocks, t[m], img_bytes / (t[m] * 1e-3) / 1e9);
         fflush(stdout);
     }
     return 0;
