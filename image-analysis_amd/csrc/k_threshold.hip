@@ -460,26 +460,29 @@ __global__ __launch_bounds__(256) void k_minmax_rgb(Job j) {
         // LDS into 48 contiguous bytes per lane (both sides conflict-free: 16-byte accesses at strides of 16 and 48 bytes).
         // Block b owns a contiguous run of rounds of its image, its four waves take them in turn.
         __shared__ lfa_u32x4 turn[4][192];
-        const int64_t rounds = (ng + 63) >> 6;
-        const int64_t per_block = (rounds + gridDim.x - 1) / gridDim.x;
-        const int64_t r_end = min(rounds, (int64_t)(blockIdx.x + 1) * per_block);
+        // (32-bit round and piece numbers -- an image has fewer than 2^32 16-byte pieces --, so that a request is three adds and
+        //  compares, not three 64-bit multiply-adds, between the arrival of one round's bytes and the next round's loads)
+        const int rounds = (int)((ng + 63) >> 6);
+        const int per_block = (rounds + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int r_end = min(rounds, (int)(blockIdx.x + 1) * per_block);
         const lfa_u32x4* img16 = (const lfa_u32x4*)base;
-        const int64_t n16 = ng * 3;
-        auto request = [&](int64_t r, lfa_u32x4 (&q)[3]) {
+        const uint32_t n16 = (uint32_t)(ng * 3);
+        auto request = [&](int r, lfa_u32x4 (&q)[3]) {
+            const uint32_t i0 = (uint32_t)r * 192u;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const int64_t i = r * 192 + 64 * k + lane;
-                q[k] = __builtin_nontemporal_load(img16 + (i < n16 ? i : r * 192));      // past the image's end: the round's first piece again
+                const uint32_t i = i0 + 64u * k + lane;
+                q[k] = __builtin_nontemporal_load(img16 + (i < n16 ? i : i0));      // past the image's end: the round's first piece again
             }
         };
-        lfa_u32x4 nx[3];                                          // (two rounds ahead measured no better: 1.54 vs 1.50 ms per 1024 images)
-        int64_t r = (int64_t)blockIdx.x * per_block + wv4;
+        lfa_u32x4 nx[3];                                          // (two rounds ahead measured no better: 1.54 vs 1.50 ms per 1024 images, twice)
+        int r = (int)blockIdx.x * per_block + wv4;
         if (r < r_end) request(r, nx);
         for (; r < r_end; r += 4) {                               // wave-uniform trip count: the reductions below need every lane
 #pragma unroll
             for (int k = 0; k < 3; ++k) turn[wv4][64 * k + lane] = nx[k];
             if (r + 4 < r_end) request(r + 4, nx);                // the next round's bytes travel while this round computes
-            const int mine48 = (r * 64 + lane < ng) ? lane : 0;   // a lane past the end works on the round's first group again: changes nothing
+            const int mine48 = ((int64_t)r * 64 + lane < ng) ? lane : 0;   // a lane past the end works on the round's first group again: changes nothing
             uint32_t w[12];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
