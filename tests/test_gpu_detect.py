@@ -913,6 +913,32 @@ def test_predicted_threshold_mode_matches_the_oracle(capi):
         e.close()
 
 
+def test_kernel_timing_filter_and_launch_stride(capi, eng):
+    """lfa_timing_enable: "*" brackets every launch, "<kernel>" that kernel only, "<kernel>/N" every N-th launch of it (what
+    bench.py uses for the dominant kernel, so that the event records between a lane's kernels do not stretch the step); a
+    stride below 1 is refused."""
+    from image_analysis_amd.synth import synth_rgb
+    img = synth_rgb(96, 128, 2, 5)
+    mm_r, mm_c = gui_params(img)
+    def calls(k):
+        for _ in range(k):
+            eng.detect(img[None], mm_r, mm_c, 10)
+        return eng.timing_read()
+    try:
+        eng.timing("*")
+        everything = calls(2)
+        assert everything["k_hist_rgb"][1] == 2 and everything["k_minmax_rgb"][1] == 2 and len(everything) > 5
+        eng.timing("k_hist_rgb")
+        only = calls(3)
+        assert list(only) == ["k_hist_rgb"] and only["k_hist_rgb"][1] == 3 and only["k_hist_rgb"][0] > 0.0
+        eng.timing("k_hist_rgb/4")
+        some = calls(9)
+        assert list(some) == ["k_hist_rgb"] and some["k_hist_rgb"][1] == 3          # launches 0, 4 and 8
+        assert capi.lib.lfa_timing_enable(eng._h, b"k_hist_rgb/0") == -1              # LFA_ERR_ARG
+    finally:
+        eng.timing(None)
+
+
 @pytest.mark.parametrize("shape", [(70, 64), (129, 128), (300, 576), (64, 192), (1, 64)])
 def test_predicted_threshold_bits_turned_in_the_run_extraction_or_by_k_mask(capi, shape):
     """Widths that are multiples of 64: an image decided from the predicted-threshold bit plane never gets a transposed mask --
